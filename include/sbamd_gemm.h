@@ -1,0 +1,212 @@
+/*
+ * sbamd_gemm.h -- C ABI of the MI355X (gfx950) GEMM engine that stands in for
+ * the BLAS-3 GEMM path of portBLAS / sycl-blas.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and 64-bit sizes and
+ * returns an `int` status (0 = success); nothing throws.  Device pointers are
+ * raw HIP device addresses (the reference's `BufferIterator + offset` /
+ * `usm_ptr + offset` collapse into a pointer that already includes the element
+ * offset).  All matrices are column-major.  Calls are asynchronous on the
+ * handle's HIP stream, like the reference's calls on its `sycl::queue`.
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   include/interface/blas3_interface.h:86-123   blas::_gemm / _gemm_batched /
+ *                                                _gemm_strided_batched
+ *   src/interface/gemm_interface.hpp:102-240     argument rules (alpha==0,
+ *                                                trans flags, stride checks)
+ *   src/interface/blas3/gemm.cpp.in:33-137       the instantiated type pairs
+ *   include/sb_handle/portblas_handle.h:46-200   SB_Handle (queue, wait)
+ *   include/portblas_helper.h:54-67,139-191      allocate / copy helpers
+ */
+#ifndef SBAMD_GEMM_H
+#define SBAMD_GEMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+
+/* Status codes.  The three INVALID_TRANS / INVALID_STRIDE groups correspond
+ * one-to-one to the std::invalid_argument messages of
+ * src/interface/gemm_interface.hpp:144-165. */
+enum {
+  SBAMD_OK = 0,
+  SBAMD_INVALID_TRANSA = 1,  /* "invalid _TransA"  gemm_interface.hpp:145 */
+  SBAMD_INVALID_TRANSB = 2,  /* "invalid _TransB"  gemm_interface.hpp:147 */
+  SBAMD_INVALID_STRIDEC = 3, /* "invalid _stridec" gemm_interface.hpp:160 */
+  SBAMD_INVALID_STRIDEA = 4, /* "invalid _stridea" gemm_interface.hpp:162 */
+  SBAMD_INVALID_STRIDEB = 5, /* "invalid _strideb" gemm_interface.hpp:164 */
+  SBAMD_INVALID_HANDLE = 6,
+  SBAMD_INVALID_VALUE = 7,   /* negative size, null pointer with work to do */
+  SBAMD_HIP_ERROR = 8,       /* a HIP runtime call failed; see last_error */
+  SBAMD_ALLOC_FAILED = 9,
+  SBAMD_NOT_SUPPORTED = 10
+};
+
+/* Batch layouts: include/operations/blas3_trees.h:59 (gemm_batch_type_t). */
+enum { SBAMD_BATCH_STRIDED = 0, SBAMD_BATCH_INTERLEAVED = 1 };
+
+/* Kernel families the dispatcher can pick; sbamd_set_kernel() pins one (tests
+ * and tuning), SBAMD_KERNEL_AUTO restores the shape-class heuristic that
+ * stands in for src/interface/blas3/backend/amd_gpu.hpp:33-290. */
+enum {
+  SBAMD_KERNEL_AUTO = 0,
+  SBAMD_KERNEL_LARGE = 1,    /* 128x128 macro tile, LDS double buffer      */
+  SBAMD_KERNEL_SMALL = 2,    /* 64x64 macro tile (batched / small shapes)  */
+  SBAMD_KERNEL_SPLITK = 3,   /* tall-skinny: K slabs -> cube -> reduction  */
+  SBAMD_KERNEL_NAIVE = 4,    /* one thread per C element, sequential k     */
+  SBAMD_KERNEL_HUGE = 5      /* 256x128 macro tile                         */
+};
+
+typedef struct sbamd_handle_s* sbamd_handle_t;
+typedef struct sbamd_event_s* sbamd_event_t;
+
+/* Human-readable text for a status code (static storage). */
+const char* sbamd_status_string(int status);
+
+/* ------------------------------------------------------------------ handle */
+
+/* Replaces blas::SB_Handle(queue) (include/sb_handle/portblas_handle.h:51-60).
+ * `device` is the HIP device ordinal.  `stream` is a hipStream_t to enqueue on,
+ * or NULL to let the handle create (and own) a non-blocking stream. */
+int sbamd_create(sbamd_handle_t* out, int device, void* stream);
+int sbamd_destroy(sbamd_handle_t h);
+
+/* SB_Handle::wait() (portblas_handle.h:175): drain the handle's stream. */
+int sbamd_wait(sbamd_handle_t h);
+
+/* SB_Handle::get_num_compute_units() (portblas_handle.h:173). */
+int sbamd_get_num_compute_units(sbamd_handle_t h, int* out);
+
+/* The hipStream_t the handle enqueues on (SB_Handle::get_queue analogue). */
+int sbamd_get_stream(sbamd_handle_t h, void** out_stream);
+
+/* Text of the most recent HIP failure seen through this handle. */
+const char* sbamd_last_error(sbamd_handle_t h);
+
+/* Pin a kernel family (SBAMD_KERNEL_*); `param` is family specific
+ * (split-K: cube depth, 0 = derive from the compute-unit count as
+ * src/operations/blas3/gemm_partial_local.hpp:191-199 does). */
+int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param);
+
+/* Which family the last GEMM call on this handle launched (SBAMD_KERNEL_*),
+ * -1 when it launched none (alpha == 0, empty problem). */
+int sbamd_last_kernel(sbamd_handle_t h);
+
+/* ------------------------------------------------------------------ events */
+
+/* The reference returns std::vector<sycl::event> from every call and takes a
+ * dependency list (portblas_handle.h:50, kernel_constructor.hpp:199).  Here an
+ * event is recorded on the handle's stream after a call, and a dependency is
+ * a stream-side wait on such an event. */
+int sbamd_event_record(sbamd_handle_t h, sbamd_event_t* out);
+int sbamd_stream_wait_event(sbamd_handle_t h, sbamd_event_t ev);
+int sbamd_event_synchronize(sbamd_event_t ev);      /* SB_Handle::wait(ev)  */
+int sbamd_event_elapsed_ms(sbamd_event_t start, sbamd_event_t stop, float* ms);
+int sbamd_event_destroy(sbamd_event_t ev);
+
+/* ------------------------------------------------------------ memory helpers */
+
+/* blas::helper::allocate / deallocate / copy_to_device / copy_to_host
+ * (include/portblas_helper.h:54-67, :139-191).  Copies are asynchronous on the
+ * handle's stream; sbamd_wait() or an event makes them visible. */
+int sbamd_malloc(sbamd_handle_t h, void** out, size_t bytes);
+int sbamd_free(sbamd_handle_t h, void* ptr);
+int sbamd_copy_to_device(sbamd_handle_t h, void* dst_dev, const void* src_host, size_t bytes);
+int sbamd_copy_to_host(sbamd_handle_t h, void* dst_host, const void* src_dev, size_t bytes);
+int sbamd_memset(sbamd_handle_t h, void* dst_dev, int byte_value, size_t bytes);
+
+/* Fill a device buffer with uniform reals in [lo, hi) from a counter-based
+ * generator (element i depends only on seed and i), so multi-GiB operands are
+ * produced without crossing PCIe.  dtype: 0 f32, 1 f64, 2 f16, 3 bf16.
+ * The reference's tests and benchmarks fill with uniform [-2, 5]
+ * (test/blas_test.hpp:137-140). */
+int sbamd_fill_uniform(sbamd_handle_t h, void* dst_dev, int64_t count, int dtype,
+                       uint64_t seed, double lo, double hi);
+
+/* -------------------------------------------------------------------- GEMM */
+
+/* C <- alpha * op(A) * op(B) + beta * C, column-major.
+ * op(X) = X for trans 'n'/'N', X^T for 't'/'T'/'c'/'C'; any other character is
+ * SBAMD_INVALID_TRANSA/B.  op(A) is m x k, op(B) is k x n, C is m x n.
+ * alpha == 0: C <- beta * C and A, B are not read (checked before the trans
+ * flags, as in gemm_interface.hpp:112-139).  beta == 0: C is never read.
+ *
+ * Replaces blas::_gemm (blas3_interface.h:86-95). Type pairs as instantiated
+ * by src/interface/blas3/gemm.cpp.in:33-137:
+ *   s: float  -> float      d: double -> double
+ *   h: half   -> half       hs: half  -> float
+ * plus bs: bfloat16 -> float, which the reference reaches only through its
+ * joint_matrix kernel on float storage
+ * (src/operations/blas3/gemm_load_store_joint_matrix.hpp:76-81). */
+int sbamd_sgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                float alpha, const float* a, int64_t lda, const float* b, int64_t ldb,
+                float beta, float* c, int64_t ldc);
+int sbamd_dgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                double alpha, const double* a, int64_t lda, const double* b, int64_t ldb,
+                double beta, double* c, int64_t ldc);
+/* half storage is passed as uint16_t bit patterns (IEEE binary16 / bfloat16);
+ * alpha and beta travel as float and are rounded to the output type. */
+int sbamd_hgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                float alpha, const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb,
+                float beta, uint16_t* c, int64_t ldc);
+int sbamd_hsgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                 float alpha, const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb,
+                 float beta, float* c, int64_t ldc);
+int sbamd_bsgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                 float alpha, const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb,
+                 float beta, float* c, int64_t ldc);
+
+/* Replaces blas::_gemm_batched (blas3_interface.h:97-109).  For
+ * SBAMD_BATCH_STRIDED the strides default to whole matrices
+ * (gemm_interface.hpp:213-219); for SBAMD_BATCH_INTERLEAVED element (r, c) of
+ * item b lives at c*ld*batch + r*batch + b
+ * (test/unittest/blas3/blas3_gemm_common.hpp:54-69). */
+int sbamd_sgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                        int64_t k, float alpha, const float* a, int64_t lda, const float* b,
+                        int64_t ldb, float beta, float* c, int64_t ldc, int64_t batch,
+                        int batch_type);
+int sbamd_dgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                        int64_t k, double alpha, const double* a, int64_t lda, const double* b,
+                        int64_t ldb, double beta, double* c, int64_t ldc, int64_t batch,
+                        int batch_type);
+
+/* Replaces blas::_gemm_strided_batched (blas3_interface.h:111-123).  Item b
+ * uses A + b*stride_a, B + b*stride_b, C + b*stride_c.  For batch > 1:
+ * stride_c < ldc*n or any negative stride is an error
+ * (gemm_interface.hpp:158-166); stride_a == 0 / stride_b == 0 broadcast. */
+int sbamd_sgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                                int64_t k, float alpha, const float* a, int64_t lda,
+                                int64_t stride_a, const float* b, int64_t ldb, int64_t stride_b,
+                                float beta, float* c, int64_t ldc, int64_t stride_c,
+                                int64_t batch);
+int sbamd_dgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                                int64_t k, double alpha, const double* a, int64_t lda,
+                                int64_t stride_a, const double* b, int64_t ldb, int64_t stride_b,
+                                double beta, double* c, int64_t ldc, int64_t stride_c,
+                                int64_t batch);
+int sbamd_hgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                                int64_t k, float alpha, const uint16_t* a, int64_t lda,
+                                int64_t stride_a, const uint16_t* b, int64_t ldb,
+                                int64_t stride_b, float beta, uint16_t* c, int64_t ldc,
+                                int64_t stride_c, int64_t batch);
+int sbamd_hsgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                                 int64_t k, float alpha, const uint16_t* a, int64_t lda,
+                                 int64_t stride_a, const uint16_t* b, int64_t ldb,
+                                 int64_t stride_b, float beta, float* c, int64_t ldc,
+                                 int64_t stride_c, int64_t batch);
+int sbamd_bsgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                                 int64_t k, float alpha, const uint16_t* a, int64_t lda,
+                                 int64_t stride_a, const uint16_t* b, int64_t ldb,
+                                 int64_t stride_b, float beta, float* c, int64_t ldc,
+                                 int64_t stride_c, int64_t batch);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* SBAMD_GEMM_H */

@@ -1,0 +1,322 @@
+/*
+ * gemm_oracle.c -- CPU restatement of the portBLAS / sycl-blas GEMM path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path may call, link or
+ * load this file: it is the checker that the HIP kernels are compared with
+ * (tests/, the smoke check, and the CPU-baseline leg of bench.py).
+ *
+ * PARITY UNPINNED in the strict sense: the reference holds no golden vectors
+ * or known-answer files for GEMM (its tests draw random inputs and compare
+ * with a system CBLAS within a tolerance, test/blas_test.hpp:107-140,
+ * test/unittest/blas3/blas3_gemm_common.hpp:163-225), and the reference
+ * itself cannot be built here (SYCL compiler and the py_gen submodule are
+ * absent).  What pins this file instead is the reference's own method: it is
+ * checked against OpenBLAS sgemm/dgemm on the reference's parameter grids with
+ * the reference's pass/fail predicate (tests/test_oracle.py), and against
+ * committed fixtures generated from it (tests/golden/).
+ *
+ * Each function cites the reference lines it follows (paths relative to the
+ * reference tree).  Built with -ffp-contract=off so that only the explicit
+ * fma() calls fuse.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* Status codes shared with include/sbamd_gemm.h (kept numerically equal so
+ * the front-end rules can be compared call by call). */
+enum {
+  ORC_OK = 0,
+  ORC_INVALID_TRANSA = 1,
+  ORC_INVALID_TRANSB = 2,
+  ORC_INVALID_STRIDEC = 3,
+  ORC_INVALID_STRIDEA = 4,
+  ORC_INVALID_STRIDEB = 5,
+  ORC_INVALID_VALUE = 7,
+  ORC_ALLOC_FAILED = 9
+};
+
+/* Which arithmetic form of the reference to follow. */
+enum {
+  /* alpha*acc + beta*C, acc = fma chain over k from zero:
+   * src/operations/blas3/gemm_ref.hpp:234-251 (naive kernel) */
+  ORC_FORM_REF = 0,
+  /* alpha * acc, acc = fma chain over k started at (beta/alpha)*C:
+   * src/operations/blas3/gemm_local.hpp:182 (beta/alpha on the host),
+   * :375-409 (scaling_c), :557-581 (store * alpha); the no_local kernels do
+   * the same (gemm_no_local_full_vec.hpp:132, gemm_no_local_partial_vec.hpp:129) */
+  ORC_FORM_LOCAL = 1,
+  /* split-K: per K slab alpha*sum (gemm_partial_local.hpp:297-355, IsBetaZero
+   * forced true by src/sb_handle/portblas_handle.hpp:345-350), slabs summed,
+   * then + beta*C (portblas_handle.hpp:383-395).  Slabs are added in index
+   * order. */
+  ORC_FORM_SPLITK = 2,
+  /* as ORC_FORM_SPLITK but slabs are combined pairwise, the shape of the
+   * reference's local-memory tree (src/operations/extension/reduction.hpp:209-224) */
+  ORC_FORM_SPLITK_TREE = 3
+};
+
+#define DEFINE_ORACLE(T, SUF, FMA)                                                              \
+  /* op(A) packed as m x k column-major, op(B) as k x n column-major: element   */             \
+  /* addressing of gemm_ref.hpp:227-243 ('n' walks lda per k, otherwise 1).     */             \
+  static void pack_a_##SUF(int ta, int64_t m, int64_t k, const T* a, int64_t lda, T* out) {     \
+    for (int64_t l = 0; l < k; ++l)                                                             \
+      for (int64_t i = 0; i < m; ++i) out[i + l * m] = ta ? a[l + i * lda] : a[i + l * lda];    \
+  }                                                                                             \
+  static void pack_b_##SUF(int tb, int64_t k, int64_t n, const T* b, int64_t ldb, T* out) {     \
+    for (int64_t j = 0; j < n; ++j)                                                             \
+      for (int64_t l = 0; l < k; ++l) out[l + j * k] = tb ? b[j + l * ldb] : b[l + j * ldb];    \
+  }                                                                                             \
+                                                                                                \
+  /* acc[i] <- fma chain over k in [k0, k1) for one column j, every row at once */             \
+  /* (per element this is exactly the sequential-k mad loop of                  */             \
+  /* gemm_ref.hpp:239-244 / gemm_local.hpp:752-772).                            */             \
+  static void column_chain_##SUF(int64_t m, int64_t k0, int64_t k1, int64_t kld, const T* pa,   \
+                                 const T* pbcol, T* acc) {                                      \
+    (void)kld;                                                                                  \
+    for (int64_t l = k0; l < k1; ++l) {                                                         \
+      const T bv = pbcol[l];                                                                    \
+      const T* acol = pa + l * m;                                                               \
+      for (int64_t i = 0; i < m; ++i) acc[i] = FMA(acol[i], bv, acc[i]);                        \
+    }                                                                                           \
+  }                                                                                             \
+                                                                                                \
+  /* One GEMM in the chosen arithmetic form.  depth / k_chunk only matter for   */             \
+  /* the split-K forms: slab s covers k in [s*k_chunk, min(k, (s+1)*k_chunk)).  */             \
+  int oracle_gemm_##SUF(int form, int ta, int tb, int64_t m, int64_t n, int64_t k, T alpha,     \
+                        const T* a, int64_t lda, const T* b, int64_t ldb, T beta, T* c,         \
+                        int64_t ldc, int64_t depth, int64_t k_chunk) {                          \
+    if (m <= 0 || n <= 0) return ORC_OK;                                                        \
+    T* pa = (T*)malloc(sizeof(T) * (size_t)(m * (k > 0 ? k : 1)));                              \
+    T* pb = (T*)malloc(sizeof(T) * (size_t)(n * (k > 0 ? k : 1)));                              \
+    if (!pa || !pb) {                                                                           \
+      free(pa);                                                                                 \
+      free(pb);                                                                                 \
+      return ORC_ALLOC_FAILED;                                                                  \
+    }                                                                                           \
+    pack_a_##SUF(ta, m, k, a, lda, pa);                                                         \
+    pack_b_##SUF(tb, k, n, b, ldb, pb);                                                         \
+    const int beta_zero = (beta == (T)0); /* gemm_interface.hpp:92 */                           \
+    int status = ORC_OK;                                                                        \
+    _Pragma("omp parallel for schedule(static)") for (int64_t j = 0; j < n; ++j) {              \
+      T* acc = (T*)malloc(sizeof(T) * (size_t)m);                                               \
+      T* part = NULL;                                                                           \
+      T* ccol = c + j * ldc;                                                                    \
+      const T* pbcol = pb + j * k;                                                              \
+      if (!acc) {                                                                               \
+        status = ORC_ALLOC_FAILED;                                                              \
+        continue;                                                                               \
+      }                                                                                         \
+      if (form == ORC_FORM_REF) {                                                               \
+        for (int64_t i = 0; i < m; ++i) acc[i] = (T)0;                                          \
+        column_chain_##SUF(m, 0, k, k, pa, pbcol, acc);                                         \
+        for (int64_t i = 0; i < m; ++i) {                                                       \
+          /* gemm_ref.hpp:247-251: beta == 0 never reads C */                                   \
+          if (beta_zero) {                                                                      \
+            ccol[i] = alpha * acc[i];                                                           \
+          } else {                                                                              \
+            const T t0 = alpha * acc[i];                                                        \
+            const T t1 = beta * ccol[i];                                                        \
+            ccol[i] = t0 + t1;                                                                  \
+          }                                                                                     \
+        }                                                                                       \
+      } else if (form == ORC_FORM_LOCAL) {                                                      \
+        const T ratio = beta / alpha; /* gemm_local.hpp:182 */                                  \
+        for (int64_t i = 0; i < m; ++i) acc[i] = beta_zero ? (T)0 : ratio * ccol[i];            \
+        column_chain_##SUF(m, 0, k, k, pa, pbcol, acc);                                         \
+        for (int64_t i = 0; i < m; ++i) ccol[i] = alpha * acc[i];                               \
+      } else {                                                                                  \
+        const int64_t nslab = depth > 0 ? depth : 1;                                            \
+        part = (T*)malloc(sizeof(T) * (size_t)(m * nslab));                                     \
+        if (!part) {                                                                            \
+          status = ORC_ALLOC_FAILED;                                                            \
+          free(acc);                                                                            \
+          continue;                                                                             \
+        }                                                                                       \
+        for (int64_t s = 0; s < nslab; ++s) {                                                   \
+          int64_t k0 = s * k_chunk, k1 = k0 + k_chunk;                                          \
+          if (k0 > k) k0 = k;                                                                   \
+          if (k1 > k) k1 = k;                                                                   \
+          for (int64_t i = 0; i < m; ++i) acc[i] = (T)0;                                        \
+          column_chain_##SUF(m, k0, k1, k, pa, pbcol, acc);                                     \
+          for (int64_t i = 0; i < m; ++i) part[i + s * m] = alpha * acc[i];                     \
+        }                                                                                       \
+        if (form == ORC_FORM_SPLITK) {                                                          \
+          for (int64_t i = 0; i < m; ++i) {                                                     \
+            T sum = part[i];                                                                    \
+            for (int64_t s = 1; s < nslab; ++s) sum = sum + part[i + s * m];                    \
+            acc[i] = sum;                                                                       \
+          }                                                                                     \
+        } else {                                                                                \
+          for (int64_t w = 1; w < nslab; w *= 2)                                                \
+            for (int64_t s = 0; s + w < nslab; s += 2 * w)                                      \
+              for (int64_t i = 0; i < m; ++i) part[i + s * m] = part[i + s * m] + part[i + (s + w) * m]; \
+          for (int64_t i = 0; i < m; ++i) acc[i] = part[i];                                     \
+        }                                                                                       \
+        for (int64_t i = 0; i < m; ++i) {                                                       \
+          if (beta_zero) {                                                                      \
+            ccol[i] = acc[i];                                                                   \
+          } else {                                                                              \
+            const T t1 = beta * ccol[i];                                                        \
+            ccol[i] = acc[i] + t1;                                                              \
+          }                                                                                     \
+        }                                                                                       \
+        free(part);                                                                             \
+      }                                                                                         \
+      free(acc);                                                                                \
+    }                                                                                           \
+    free(pa);                                                                                   \
+    free(pb);                                                                                   \
+    return status;                                                                              \
+  }                                                                                             \
+                                                                                                \
+  /* C = beta*C over a rows x cols window: _scal_matrix multiplies               */            \
+  /* (src/interface/blas1_interface.hpp:498-506), the vector _scal with a zero   */            \
+  /* factor assigns zero (:444-448).                                             */            \
+  static void scale_window_##SUF(T* c, int64_t rows, int64_t cols, int64_t ld, T beta,          \
+                                 int assign_zero) {                                             \
+    for (int64_t j = 0; j < cols; ++j)                                                          \
+      for (int64_t i = 0; i < rows; ++i)                                                        \
+        c[i + j * ld] = assign_zero ? (T)0 : beta * c[i + j * ld];                              \
+  }                                                                                             \
+                                                                                                \
+  /* The whole front end: src/interface/gemm_interface.hpp:102-185.              */            \
+  /* batch_type: 0 strided, 1 interleaved (element (r, c) of item b at           */            \
+  /* c*ld*batch + r*batch + b, test/unittest/blas3/blas3_gemm_common.hpp:54-69). */            \
+  int oracle_gemm_backend_##SUF(int form, char transa, char transb, int64_t m, int64_t n,       \
+                                int64_t k, T alpha, const T* a, int64_t lda, int64_t stride_a,  \
+                                const T* b, int64_t ldb, int64_t stride_b, T beta, T* c,        \
+                                int64_t ldc, int64_t stride_c, int64_t batch, int batch_type,   \
+                                int64_t depth, int64_t k_chunk) {                               \
+    if (m < 0 || n < 0 || k < 0 || batch < 0) return ORC_INVALID_VALUE;                         \
+    if (alpha == (T)0) { /* :112-139 */                                                         \
+      if (m == 0 || n == 0 || batch == 0) return ORC_OK;                                        \
+      const int64_t size_c = ldc * n;                                                           \
+      if (batch_type == 1 && batch > 1) {                                                       \
+        if (!(beta == (T)1)) scale_window_##SUF(c, m * batch, n, ldc * batch, beta, 0);         \
+      } else if (size_c == stride_c) {                                                          \
+        if (ldc == m) {                                                                         \
+          scale_window_##SUF(c, size_c * batch, 1, size_c * batch, beta, beta == (T)0);         \
+        } else if (!(beta == (T)1)) {                                                           \
+          scale_window_##SUF(c, m, n * batch, ldc, beta, 0);                                    \
+        }                                                                                       \
+      } else if (!(beta == (T)1)) {                                                             \
+        for (int64_t z = 0; z < batch; ++z) scale_window_##SUF(c + z * stride_c, m, n, ldc, beta, 0); \
+      }                                                                                         \
+      return ORC_OK;                                                                            \
+    }                                                                                           \
+    if (transa >= 'A' && transa <= 'Z') transa = (char)(transa - 'A' + 'a'); /* :141-142 */     \
+    if (transb >= 'A' && transb <= 'Z') transb = (char)(transb - 'A' + 'a');                    \
+    if (transa != 'n' && transa != 't' && transa != 'c') return ORC_INVALID_TRANSA;             \
+    if (transb != 'n' && transb != 't' && transb != 'c') return ORC_INVALID_TRANSB;             \
+    const int ta = transa != 'n', tb = transb != 'n'; /* :150-151 */                            \
+    if (batch > 1 && batch_type == 0) {               /* :158-166 */                            \
+      if (stride_c < ldc * n || stride_c < 0) return ORC_INVALID_STRIDEC;                       \
+      if (stride_a < 0) return ORC_INVALID_STRIDEA;                                             \
+      if (stride_b < 0) return ORC_INVALID_STRIDEB;                                             \
+    }                                                                                           \
+    if (m == 0 || n == 0 || batch == 0) return ORC_OK;                                          \
+    if (batch_type == 1 && batch > 1) {                                                         \
+      /* interleaved: item z is the strided problem with every index scaled by   */            \
+      /* batch; gather it, solve it, scatter C back.                             */            \
+      const int64_t ar = ta ? k : m, ac = ta ? m : k;                                           \
+      const int64_t br = tb ? n : k, bc = tb ? k : n;                                           \
+      T* ta_ = (T*)malloc(sizeof(T) * (size_t)(ar * ac > 0 ? ar * ac : 1));                     \
+      T* tb_ = (T*)malloc(sizeof(T) * (size_t)(br * bc > 0 ? br * bc : 1));                     \
+      T* tc_ = (T*)malloc(sizeof(T) * (size_t)(m * n));                                         \
+      if (!ta_ || !tb_ || !tc_) {                                                               \
+        free(ta_);                                                                              \
+        free(tb_);                                                                              \
+        free(tc_);                                                                              \
+        return ORC_ALLOC_FAILED;                                                                \
+      }                                                                                         \
+      int st = ORC_OK;                                                                          \
+      for (int64_t z = 0; z < batch && st == ORC_OK; ++z) {                                     \
+        for (int64_t cc = 0; cc < ac; ++cc)                                                     \
+          for (int64_t r = 0; r < ar; ++r) ta_[r + cc * ar] = a[cc * lda * batch + r * batch + z]; \
+        for (int64_t cc = 0; cc < bc; ++cc)                                                     \
+          for (int64_t r = 0; r < br; ++r) tb_[r + cc * br] = b[cc * ldb * batch + r * batch + z]; \
+        for (int64_t cc = 0; cc < n; ++cc)                                                      \
+          for (int64_t r = 0; r < m; ++r) tc_[r + cc * m] = c[cc * ldc * batch + r * batch + z]; \
+        st = oracle_gemm_##SUF(form, ta, tb, m, n, k, alpha, ta_, ar, tb_, br, beta, tc_, m,    \
+                               depth, k_chunk);                                                 \
+        for (int64_t cc = 0; cc < n; ++cc)                                                      \
+          for (int64_t r = 0; r < m; ++r) c[cc * ldc * batch + r * batch + z] = tc_[r + cc * m]; \
+      }                                                                                         \
+      free(ta_);                                                                                \
+      free(tb_);                                                                                \
+      free(tc_);                                                                                \
+      return st;                                                                                \
+    }                                                                                           \
+    for (int64_t z = 0; z < batch; ++z) { /* gemm_local.hpp:290-292 */                          \
+      int st = oracle_gemm_##SUF(form, ta, tb, m, n, k, alpha, a + z * stride_a, lda,           \
+                                 b + z * stride_b, ldb, beta, c + z * stride_c, ldc, depth,     \
+                                 k_chunk);                                                      \
+      if (st != ORC_OK) return st;                                                              \
+    }                                                                                           \
+    return ORC_OK;                                                                              \
+  }
+
+DEFINE_ORACLE(float, f32, fmaf)
+DEFINE_ORACLE(double, f64, fma)
+
+/* Default strides of _gemm_batched (src/interface/gemm_interface.hpp:213-219). */
+void oracle_default_strides(char transa, char transb, int64_t m, int64_t n, int64_t k, int64_t lda,
+                            int64_t ldb, int64_t ldc, int64_t* sa, int64_t* sb, int64_t* sc) {
+  if (transa >= 'A' && transa <= 'Z') transa = (char)(transa - 'A' + 'a');
+  if (transb >= 'A' && transb <= 'Z') transb = (char)(transb - 'A' + 'a');
+  *sa = (transa != 'n') ? m * lda : k * lda;
+  *sb = (transb != 'n') ? ldb * k : n * ldb;
+  *sc = ldc * n;
+}
+
+/* High-precision truth for error bounds: C_exact = alpha*sum + beta*C in long
+ * double from double-converted inputs, and the magnitude sum
+ * |alpha|*sum|a||b| + |beta||c| that scales the k-dependent bound.  Inputs are
+ * given as doubles (exact images of the float / half data). */
+int oracle_gemm_truth(int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha,
+                      const double* a, int64_t lda, const double* b, int64_t ldb, double beta,
+                      const double* c, int64_t ldc, double* out, double* mag, int64_t ldo) {
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < n; ++j) {
+    for (int64_t i = 0; i < m; ++i) {
+      long double s = 0.0L, sa = 0.0L;
+      for (int64_t l = 0; l < k; ++l) {
+        const long double av = ta ? a[l + i * lda] : a[i + l * lda];
+        const long double bv = tb ? b[j + l * ldb] : b[l + j * ldb];
+        s += av * bv;
+        sa += fabsl(av * bv);
+      }
+      long double r = (long double)alpha * s;
+      long double ra = fabsl((long double)alpha) * sa;
+      if (beta != 0.0) {
+        r += (long double)beta * c[i + j * ldc];
+        ra += fabsl((long double)beta * c[i + j * ldc]);
+      }
+      out[i + j * ldo] = (double)r;
+      mag[i + j * ldo] = (double)ra;
+    }
+  }
+  return ORC_OK;
+}
+
+/* The reference's element comparison (common/include/common/float_comparison.hpp:163-188):
+ * returns the index of the first mismatch or -1.  abs_margin / rel_margin are
+ * the per-type margins of :100-158. */
+int64_t oracle_compare_f64(const double* vec, const double* ref, int64_t count, double abs_margin,
+                           double rel_margin) {
+  for (int64_t i = 0; i < count; ++i) {
+    const double x = vec[i], y = ref[i];
+    if (x == y) continue;
+    if ((isnan(x) && isnan(y)) || (isinf(x) && isinf(y))) continue;
+    const double d = fabs(x - y);
+    if (x == 0.0 || y == 0.0 || d < abs_margin) {
+      if (d < abs_margin) continue;
+      return i;
+    }
+    if (d / (fabs(x) + fabs(y)) < rel_margin) continue;
+    return i;
+  }
+  return -1;
+}

@@ -1,0 +1,198 @@
+// Host-side kernel selection and launch for the fp32 / fp64 MFMA kernels.
+//
+// Stands in for the reference's per-target dispatch header
+// (src/interface/blas3/backend/amd_gpu.hpp:33-290), its launcher
+// (src/interface/gemm_launcher.hpp:37-69) and the tall-skinny driver
+// (src/sb_handle/portblas_handle.hpp:296-403).  The shape classes are the
+// reference's (tall-skinny / small-or-batched / large); the tile shapes are
+// chosen for CDNA4 MFMA instead of the MI210 auto-tuner table.
+#pragma once
+
+#include <algorithm>
+
+#include "gemm_mfma.hpp"
+#include "sbamd_internal.hpp"
+
+namespace sbamd {
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <typename T>
+inline bool vec_ok(const T* p, int64_t ld, int64_t stride, int64_t batch) {
+  constexpr int V = 16 / sizeof(T);
+  return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % V == 0) &&
+         (batch <= 1 || stride % V == 0);
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+hipError_t launch_one(const GemmArgs<T>& g, int64_t nz, hipStream_t stream) {
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
+  auto kernel = gemm_mfma_kernel<T, BM, BN, BK, WM, WN, TA, TB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(K::LDS_BYTES));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * nz;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(K::NT), K::LDS_BYTES, stream, g);
+  return hipGetLastError();
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN>
+hipError_t launch_tile(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
+  g.tiles_m = int32_t(ceil_div(g.m, BM));
+  g.tiles_n = int32_t(ceil_div(g.n, BN));
+  const int64_t nz = g.split_k > 1 ? g.split_k : g.batch;
+  if (ta) {
+    return tb ? launch_one<T, BM, BN, BK, WM, WN, true, true>(g, nz, stream)
+              : launch_one<T, BM, BN, BK, WM, WN, true, false>(g, nz, stream);
+  }
+  return tb ? launch_one<T, BM, BN, BK, WM, WN, false, true>(g, nz, stream)
+            : launch_one<T, BM, BN, BK, WM, WN, false, false>(g, nz, stream);
+}
+
+template <typename T>
+hipError_t launch_naive(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream) {
+  const int64_t total = g.m * g.n * g.batch;
+  const int64_t grid = ceil_div(total, 256);
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (ta) {
+    if (tb) hipLaunchKernelGGL((gemm_naive_kernel<T, true, true>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_naive_kernel<T, true, false>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  } else {
+    if (tb) hipLaunchKernelGGL((gemm_naive_kernel<T, false, true>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_naive_kernel<T, false, false>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  }
+  return hipGetLastError();
+}
+
+// Tile families.  BK is 16 for fp32 and 8 for fp64 in the small family so a
+// 64 x 64 x 64 batched item is staged in four steps; the large families take a
+// deeper K step so K-major operands are fetched in whole 128-byte lines.
+template <typename T>
+struct Tiles;
+template <>
+struct Tiles<float> {
+  static constexpr int LARGE_BK = 32, SMALL_BK = 16, HUGE_BK = 16;
+};
+template <>
+struct Tiles<double> {
+  static constexpr int LARGE_BK = 16, SMALL_BK = 8, HUGE_BK = 8;
+};
+
+// The reference's tall-skinny predicate (amd_gpu.hpp:77-81).
+inline bool is_tall_skinny(int64_t m, int64_t n, int64_t k, int64_t batch) {
+  return batch == 1 && ((k > 8192 && m <= 1024 && n <= 1024) || (k > 1024 && m <= 256 && n <= 256));
+}
+
+template <typename T>
+hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
+  GemmArgs<T> g;
+  g.a = p.a;
+  g.b = p.b;
+  g.c = p.c;
+  g.m = p.m;
+  g.n = p.n;
+  g.k = p.k;
+  g.lda = p.lda;
+  g.ldb = p.ldb;
+  g.ldc = p.ldc;
+  g.stride_a = p.stride_a;
+  g.stride_b = p.stride_b;
+  g.stride_c = p.stride_c;
+  g.batch = int32_t(p.batch);
+  g.split_k = 1;
+  g.k_chunk = p.k;
+  g.slice_stride = 0;
+  g.tiles_m = g.tiles_n = 0;
+  g.vec_a = vec_ok(p.a, p.lda, p.stride_a, p.batch) ? 1 : 0;
+  g.vec_b = vec_ok(p.b, p.ldb, p.stride_b, p.batch) ? 1 : 0;
+  g.alpha = p.alpha;
+  g.beta = p.beta;
+  g.beta_zero = p.beta_zero ? 1 : 0;
+
+  const int cus = h->compute_units > 0 ? h->compute_units : 256;
+
+  int family = h->kernel_override;
+  if (family == SBAMD_KERNEL_AUTO) {
+    if (is_tall_skinny(p.m, p.n, p.k, p.batch)) {
+      family = SBAMD_KERNEL_SPLITK;
+    } else {
+      // Large tiles only when they still give every compute unit work.
+      const int64_t large_tiles = ceil_div(p.m, 128) * ceil_div(p.n, 128) * p.batch;
+      family = large_tiles >= cus ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
+    }
+  }
+
+  if (family == SBAMD_KERNEL_SPLITK) {
+    // Tile for the partial products: the large tile once M and N fill it.
+    const bool big = p.m > 64 && p.n > 64;
+    const int bm = big ? 128 : 64;
+    const int bk = big ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
+    const int64_t tiles_mn = ceil_div(p.m, bm) * ceil_div(p.n, bm);
+    // Cube depth: four workgroups per compute unit
+    // (src/operations/blas3/gemm_partial_local.hpp:191-199) unless pinned.
+    int64_t depth = h->kernel_param > 0 ? h->kernel_param : ceil_div(4 * int64_t(cus), tiles_mn);
+    // The reference falls back to one final partial kernel for shallow K
+    // (portblas_handle.hpp:323-331).
+    if (h->kernel_param <= 0 && (depth == 1 || p.k <= 2048)) depth = 1;
+    if (p.batch != 1) depth = 1;
+    // K slab of one slice: whole K tiles (gemm_partial_local.hpp:174, :253).
+    const int64_t k_chunk = std::max<int64_t>(bk, bk * ceil_div(p.k, int64_t(bk) * depth));
+    depth = std::max<int64_t>(1, ceil_div(p.k, k_chunk));
+    if (depth > 1) {
+      const int64_t slice = p.m * p.n;
+      hipError_t e = ensure_scratch(h, size_t(slice) * depth * sizeof(T));
+      if (e != hipSuccess) return e;
+      GemmArgs<T> gp = g;
+      gp.c = static_cast<T*>(h->scratch);
+      gp.ldc = p.m;
+      gp.split_k = int32_t(depth);
+      gp.k_chunk = k_chunk;
+      gp.slice_stride = slice;
+      gp.beta_zero = 1;
+      e = big ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2>(gp, p.ta, p.tb, h->stream)
+              : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
+      if (e != hipSuccess) return e;
+      const int64_t grid = ceil_div(slice, 256);
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)grid), dim3(256), 0, h->stream,
+                         static_cast<const T*>(h->scratch), slice, int(depth), p.c, p.m, p.n,
+                         p.ldc, p.beta, g.beta_zero);
+      h->last_kernel = SBAMD_KERNEL_SPLITK;
+      return hipGetLastError();
+    }
+    family = big ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
+  }
+
+  h->last_kernel = family;
+  switch (family) {
+    case SBAMD_KERNEL_LARGE:
+      return launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2>(g, p.ta, p.tb, h->stream);
+    case SBAMD_KERNEL_HUGE:
+      return launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(g, p.ta, p.tb, h->stream);
+    case SBAMD_KERNEL_SMALL:
+      return launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(g, p.ta, p.tb, h->stream);
+    case SBAMD_KERNEL_NAIVE:
+      return launch_naive<T>(g, p.ta, p.tb, h->stream);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+template <typename T>
+hipError_t run_scale_real(Handle* h, T* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride,
+                          int64_t batch, T beta, bool assign_zero) {
+  const int64_t total = rows * cols * batch;
+  if (total <= 0) return hipSuccess;
+  const int64_t grid = ceil_div(total, 256);
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((scale_matrix_kernel<T>), dim3((unsigned)grid), dim3(256), 0, h->stream, c,
+                     rows, cols, ld, stride, batch, beta, assign_zero ? 1 : 0);
+  return hipGetLastError();
+}
+
+}  // namespace sbamd

@@ -1,0 +1,417 @@
+// LDS-tiled MFMA GEMM for gfx950 (fp32 and fp64 storage).
+//
+// One workgroup of WM*WN wavefronts owns a BM x BN tile of C and walks K in
+// steps of BK through two LDS buffers.  Both operand tiles are kept in LDS as
+// [k][mn] images (the M or N index fastest), so a wavefront's MFMA fragment is
+// one conflict-free row read per lane and the matrix instruction consumes k in
+// increasing order: the accumulator of every C element is the plain
+// fused-multiply-add chain over k = 0, 1, 2, ... that the reference kernels
+// build with sycl::mad (src/operations/blas3/gemm_ref.hpp:234-251,
+// src/operations/blas3/gemm_local.hpp:737-773), which makes the result
+// reproducible bit for bit on the CPU.
+//
+// The role this kernel plays in the reference is that of
+// Gemm<..., local, standard, ...> (src/operations/blas3/gemm_local.hpp:74-875)
+// and, with SPLIT-K slices, GemmPartial (gemm_partial_local.hpp:32-457).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sbamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// Arguments shared by every kernel in this file.  Pointers are typed in the
+// kernels; sizes are 64-bit so 65536 x 65536 operands index correctly.
+template <typename T>
+struct GemmArgs {
+  const T* a;
+  const T* b;
+  T* c;
+  int64_t m, n, k;
+  int64_t lda, ldb, ldc;
+  int64_t stride_a, stride_b, stride_c;  // per batch item (elements)
+  int32_t batch;                         // >= 1
+  int32_t split_k;                       // >= 1; > 1 only with batch == 1
+  int64_t k_chunk;                       // K range of one split-K slice
+  int64_t slice_stride;                  // elements between slices of the cube
+  int32_t tiles_m, tiles_n;
+  int32_t vec_a, vec_b;                  // 16-byte loads are legal for A / B
+  T alpha, beta;
+  int32_t beta_zero;                     // never read C
+};
+
+// ---------------------------------------------------------------- MFMA shapes
+template <typename T>
+struct Mfma;
+
+// v_mfma_f32_32x32x2_f32: lane l feeds op0[i = l & 31][k = l >> 5] and
+// op1[k = l >> 5][j = l & 31]; it receives D[i][j = l & 31] for
+// i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), r = 0..15.
+template <>
+struct Mfma<float> {
+  static constexpr int T = 32;  // square tile edge
+  static constexpr int TK = 2;  // k consumed per instruction
+  static constexpr int NACC = 16;
+  using acc_t = f32x16;
+  using vec_t = f32x4;
+  static constexpr int V = 4;  // elements per 16-byte vector
+  __device__ static inline acc_t mma(float op0, float op1, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(op0, op1, c, 0, 0, 0);
+  }
+  __device__ static inline int lane_mn(int lane) { return lane & 31; }
+  __device__ static inline int lane_k(int lane) { return lane >> 5; }
+  __device__ static inline int acc_i(int r, int lane) {
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  }
+  static constexpr int PAD = 4;  // LDS row = BMN + PAD elements
+};
+
+// v_mfma_f64_16x16x4_f64: lane l feeds op0[i = l & 15][k = l >> 4] and
+// op1[k = l >> 4][j = l & 15]; it receives D[i][j = l & 15] for
+// i = (l >> 4) + 4 * r, r = 0..3.
+template <>
+struct Mfma<double> {
+  static constexpr int T = 16;
+  static constexpr int TK = 4;
+  static constexpr int NACC = 4;
+  using acc_t = f64x4;
+  using vec_t = f64x2;
+  static constexpr int V = 2;
+  __device__ static inline acc_t mma(double op0, double op1, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(op0, op1, c, 0, 0, 0);
+  }
+  __device__ static inline int lane_mn(int lane) { return lane & 15; }
+  __device__ static inline int lane_k(int lane) { return lane >> 4; }
+  __device__ static inline int acc_i(int r, int lane) { return (lane >> 4) + 4 * r; }
+  // Row stride = 16 (mod 32) doubles: the 16 lanes of k and the 16 lanes of
+  // k + 1 in one ds_read_b64 lane group land on disjoint halves of the 64 banks.
+  static constexpr int PAD = 16;
+};
+
+// ------------------------------------------------------------- tile loading
+//
+// An operand tile covers BMN indices along M (or N) and BK along K.
+// KMAJOR = the K index is the contiguous one in global memory
+//          (A with trans != 'n', B with trans == 'n').
+// Each thread moves NV 16-byte vectors per tile: global -> registers ->
+// LDS image [BK][BMN + PAD].
+template <typename T, int BMN, int BK, int NT, bool KMAJOR>
+struct TileLoader {
+  using M = Mfma<T>;
+  static constexpr int V = M::V;
+  static constexpr int S = BMN + M::PAD;
+  static constexpr int NVEC = BMN * BK / V;
+  static_assert(NVEC % NT == 0, "tile must split evenly over the workgroup");
+  static constexpr int NV = NVEC / NT;
+  static constexpr int PER_ROW = KMAJOR ? (BK / V) : (BMN / V);
+
+  T reg[NV][V];
+
+  // mn0: first M/N index of the tile, mn_lim: matrix extent along M/N,
+  // k0: first k of the tile, k_end: end of this workgroup's K range.
+  // fast: the tile is interior, fully inside K, and 16-byte loads are legal.
+  __device__ inline void load(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim,
+                              int64_t k0, int64_t k_end, bool fast, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / PER_ROW;
+      const int col = (v % PER_ROW) * V;
+      // KMAJOR: row walks mn, col walks k.  Otherwise row walks k, col mn.
+      const int64_t mn = mn0 + (KMAJOR ? row : col);
+      const int64_t kk = k0 + (KMAJOR ? col : row);
+      if (fast) {
+        const T* p = KMAJOR ? (x + kk + mn * ld) : (x + mn + kk * ld);
+        const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(p);
+#pragma unroll
+        for (int e = 0; e < V; ++e) reg[i][e] = vv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          int64_t mne = KMAJOR ? mn : (mn + e);
+          const int64_t ke = KMAJOR ? (kk + e) : kk;
+          // Rows/columns past the matrix edge re-read the last valid one: they
+          // only feed C elements that are never stored.  k past the end must
+          // contribute exactly zero.
+          mne = mne < mn_lim ? mne : (mn_lim - 1);
+          T val = T(0);
+          if (ke < k_end) val = KMAJOR ? x[ke + mne * ld] : x[mne + ke * ld];
+          reg[i][e] = val;
+        }
+      }
+    }
+  }
+
+  __device__ inline void store(T* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / PER_ROW;
+      const int col = (v % PER_ROW) * V;
+      if (KMAJOR) {
+        // transpose on the way in: V scalar stores down a column of the image
+#pragma unroll
+        for (int e = 0; e < V; ++e) lds[(col + e) * S + row] = reg[i][e];
+      } else {
+        typename M::vec_t vv;
+#pragma unroll
+        for (int e = 0; e < V; ++e) vv[e] = reg[i][e];
+        *reinterpret_cast<typename M::vec_t*>(lds + row * S + col) = vv;
+      }
+    }
+  }
+};
+
+// XCD-aware, bijective remap of the linear workgroup id: workgroups are dealt
+// round-robin over the 8 XCDs, so give each XCD one contiguous run of logical
+// ids (neighbouring tiles then share an L2).
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// Rows of tiles are walked in bands of GROUP_M so that a run of consecutive
+// logical ids touches few distinct A and B panels.
+constexpr int GROUP_M = 8;
+__device__ inline void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int band = GROUP_M * tiles_n;
+  const int g = t / band;
+  const int first_m = g * GROUP_M;
+  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+  const int in = t - g * band;
+  tm = first_m + in % gsz;
+  tn = in / gsz;
+}
+
+// ------------------------------------------------------------------ the kernel
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+struct GemmTile {
+  using M = Mfma<T>;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int WTM = BM / WM;  // wavefront tile
+  static constexpr int WTN = BN / WN;
+  static constexpr int MI = WTM / M::T;
+  static constexpr int NI = WTN / M::T;
+  static_assert(MI >= 1 && NI >= 1, "wave tile smaller than one MFMA");
+  static_assert(BK % M::TK == 0, "BK must hold whole MFMA k-steps");
+  // A is K-major when transposed; B is K-major when NOT transposed.
+  using LoadA = TileLoader<T, BM, BK, NT, TA>;
+  using LoadB = TileLoader<T, BN, BK, NT, !TB>;
+  static constexpr int SA = LoadA::S;
+  static constexpr int SB = LoadB::S;
+  static constexpr int A_ELEMS = BK * SA;
+  static constexpr int B_ELEMS = BK * SB;
+  static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
+  static constexpr size_t LDS_BYTES = 2 * size_t(STAGE_ELEMS) * sizeof(T);
+};
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+__global__ void __launch_bounds__(WM* WN * 64)
+    gemm_mfma_kernel(const GemmArgs<T> g) {
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
+  using M = Mfma<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM;
+  const int wn = wave / WM;
+
+  // ---- which tile / batch item / K slice
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = logical / ntiles;
+  int tm, tn;
+  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
+  const int64_t m0 = int64_t(tm) * BM;
+  const int64_t n0 = int64_t(tn) * BN;
+
+  const T* a = g.a;
+  const T* b = g.b;
+  T* c = g.c;
+  int64_t k_begin = 0, k_end = g.k;
+  if (g.split_k > 1) {
+    k_begin = int64_t(z) * g.k_chunk;
+    k_end = k_begin + g.k_chunk < g.k ? k_begin + g.k_chunk : g.k;
+    c += int64_t(z) * g.slice_stride;
+  } else {
+    a += int64_t(z) * g.stride_a;
+    b += int64_t(z) * g.stride_b;
+    c += int64_t(z) * g.stride_c;
+  }
+
+  const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
+  const bool fast_a = interior && g.vec_a;
+  const bool fast_b = interior && g.vec_b;
+
+  typename M::acc_t acc[K::MI][K::NI];
+#pragma unroll
+  for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = T(0);
+
+  typename K::LoadA la;
+  typename K::LoadB lb;
+
+  const int64_t klen = k_end > k_begin ? k_end - k_begin : 0;
+  const int nk = int((klen + BK - 1) / BK);
+
+  if (nk > 0) {
+    const bool full0 = k_begin + BK <= k_end;
+    la.load(a, g.lda, m0, g.m, k_begin, k_end, fast_a && full0, tid);
+    lb.load(b, g.ldb, n0, g.n, k_begin, k_end, fast_b && full0, tid);
+    la.store(smem, tid);
+    lb.store(smem + K::A_ELEMS, tid);
+  }
+  __syncthreads();
+
+  const int frag_mn = M::lane_mn(lane);
+  const int frag_k = M::lane_k(lane);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const T* as = smem + cur * K::STAGE_ELEMS;
+    const T* bs = as + K::A_ELEMS;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      const int64_t k0 = k_begin + int64_t(kt + 1) * BK;
+      const bool full = k0 + BK <= k_end;
+      la.load(a, g.lda, m0, g.m, k0, k_end, fast_a && full, tid);
+      lb.load(b, g.ldb, n0, g.n, k0, k_end, fast_b && full, tid);
+    }
+
+#pragma unroll
+    for (int s = 0; s < BK / M::TK; ++s) {
+      const int kl = s * M::TK + frag_k;
+      T fa[K::MI], fb[K::NI];
+#pragma unroll
+      for (int i = 0; i < K::MI; ++i) fa[i] = as[kl * K::SA + wm * K::WTM + i * M::T + frag_mn];
+#pragma unroll
+      for (int j = 0; j < K::NI; ++j) fb[j] = bs[kl * K::SB + wn * K::WTN + j * M::T + frag_mn];
+      // op0 carries the N index and op1 the M index, so each lane ends up
+      // holding one M index (contiguous in column-major C) across its lanes.
+#pragma unroll
+      for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < K::NI; ++j) acc[i][j] = M::mma(fb[j], fa[i], acc[i][j]);
+    }
+
+    if (more) {
+      T* nxt = smem + (cur ^ 1) * K::STAGE_ELEMS;
+      la.store(nxt, tid);
+      lb.store(nxt + K::A_ELEMS, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C = alpha * acc (+ beta * C); products and the sum round
+  // separately (the file is built with -ffp-contract=off).
+  const T alpha = g.alpha, beta = g.beta;
+  const bool read_c = !g.beta_zero && g.split_k <= 1;
+#pragma unroll
+  for (int i = 0; i < K::MI; ++i) {
+    const int64_t mm = m0 + wm * K::WTM + i * M::T + frag_mn;
+#pragma unroll
+    for (int j = 0; j < K::NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int64_t nn = n0 + wn * K::WTN + j * M::T + M::acc_i(r, lane);
+        if (mm < g.m && nn < g.n) {
+          T* p = c + mm + nn * g.ldc;
+          T out = alpha * acc[i][j][r];
+          if (read_c) {
+            const T bc = beta * (*p);
+            out = out + bc;
+          }
+          *p = out;
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------- split-K cube reduction
+// out = sum over slices of the cube (+ beta * C).  Slices are added in index
+// order, one C element per thread.  Counterpart of the reference's
+// Reduction<AddOperator, outer> + the `temp + beta*C` assignment
+// (src/operations/extension/reduction.hpp:152-230,
+//  src/sb_handle/portblas_handle.hpp:354-395).
+template <typename T>
+__global__ void __launch_bounds__(256)
+    splitk_reduce_kernel(const T* __restrict__ cube, int64_t slice_stride, int depth, T* c,
+                         int64_t m, int64_t n, int64_t ldc, T beta, int beta_zero) {
+  const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= m * n) return;
+  const int64_t row = idx % m;
+  const int64_t col = idx / m;
+  T sum = cube[idx];
+  for (int d = 1; d < depth; ++d) sum = sum + cube[idx + int64_t(d) * slice_stride];
+  T* p = c + row + col * ldc;
+  if (!beta_zero) {
+    const T bc = beta * (*p);
+    sum = sum + bc;
+  }
+  *p = sum;
+}
+
+__device__ inline float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ inline double fma_rn(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ------------------------------------------------------------- naive kernel
+// One thread per C element, k in increasing order, fused multiply-add:
+// the device twin of the reference's naive Gemm::eval
+// (src/operations/blas3/gemm_ref.hpp:195-260).
+template <typename T, bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_naive_kernel(const GemmArgs<T> g) {
+  const int64_t per = g.m * g.n;
+  const int64_t gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= per * g.batch) return;
+  const int64_t z = gid / per;
+  const int64_t idx = gid - z * per;
+  const int64_t row = idx % g.m;
+  const int64_t col = idx / g.m;
+  const T* a = g.a + z * g.stride_a + (TA ? row * g.lda : row);
+  const T* b = g.b + z * g.stride_b + (TB ? col : col * g.ldb);
+  const int64_t sa = TA ? 1 : g.lda;
+  const int64_t sb = TB ? g.ldb : 1;
+  T acc = T(0);
+  for (int64_t k = 0; k < g.k; ++k) acc = fma_rn(a[k * sa], b[k * sb], acc);
+  T* p = g.c + z * g.stride_c + row + col * g.ldc;
+  T out = g.alpha * acc;
+  if (!g.beta_zero) {
+    const T bc = g.beta * (*p);
+    out = out + bc;
+  }
+  *p = out;
+}
+
+// ---------------------------------------------------------------- C = beta*C
+// alpha == 0 path (src/interface/gemm_interface.hpp:112-139).  assign_zero is
+// the whole-vector _scal with a zero factor, which stores zeros
+// (src/interface/blas1_interface.hpp:444-448); otherwise every element of the
+// rows x cols window is multiplied, so NaN * 0 stays NaN (:498-506).
+template <typename T>
+__global__ void __launch_bounds__(256)
+    scale_matrix_kernel(T* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride,
+                        int64_t batch, T beta, int assign_zero) {
+  const int64_t per = rows * cols;
+  const int64_t gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= per * batch) return;
+  const int64_t z = gid / per;
+  const int64_t idx = gid - z * per;
+  T* p = c + z * stride + (idx % rows) + (idx / rows) * ld;
+  *p = assign_zero ? T(0) : beta * (*p);
+}
+
+}  // namespace sbamd

@@ -1,0 +1,439 @@
+// C ABI of the GEMM engine: handle, events, memory helpers and the GEMM front
+// end.  The front end restates, rule for rule, what the reference does between
+// its public entry points and the kernel launch
+// (src/interface/gemm_interface.hpp:102-240).
+#include <cctype>
+#include <cstring>
+#include <new>
+
+#include "sbamd_internal.hpp"
+
+struct sbamd_handle_s {
+  sbamd::Handle impl;
+};
+struct sbamd_event_s {
+  hipEvent_t ev;
+};
+
+namespace sbamd {
+
+hipError_t ensure_scratch(Handle* h, size_t bytes) {
+  std::lock_guard<std::mutex> lock(h->mu);
+  if (bytes <= h->scratch_bytes) return hipSuccess;
+  if (h->scratch) {
+    // Earlier work on the stream may still read the old buffer.
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return e;
+    e = hipFree(h->scratch);
+    if (e != hipSuccess) return e;
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+  }
+  const size_t rounded = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+  hipError_t e = hipMalloc(&h->scratch, rounded);
+  if (e != hipSuccess) return e;
+  h->scratch_bytes = rounded;
+  return hipSuccess;
+}
+
+namespace {
+
+int fail_hip(Handle* h, hipError_t e, const char* what) {
+  h->last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return e == hipErrorOutOfMemory ? SBAMD_ALLOC_FAILED : SBAMD_HIP_ERROR;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename TOut>
+hipError_t scale_c(Handle* h, TOut* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride,
+                   int64_t batch, TOut beta, bool assign_zero);
+template <>
+hipError_t scale_c<float>(Handle* h, float* c, int64_t rows, int64_t cols, int64_t ld,
+                          int64_t stride, int64_t batch, float beta, bool assign_zero) {
+  return run_scale_f32(h, c, rows, cols, ld, stride, batch, beta, assign_zero);
+}
+template <>
+hipError_t scale_c<double>(Handle* h, double* c, int64_t rows, int64_t cols, int64_t ld,
+                           int64_t stride, int64_t batch, double beta, bool assign_zero) {
+  return run_scale_f64(h, c, rows, cols, ld, stride, batch, beta, assign_zero);
+}
+
+inline hipError_t run_backend(Handle* h, const Problem<float, float>& p) { return run_gemm_f32(h, p); }
+inline hipError_t run_backend(Handle* h, const Problem<double, double>& p) { return run_gemm_f64(h, p); }
+
+// The reference's _gemm_backend (src/interface/gemm_interface.hpp:102-185),
+// in the same order: alpha == 0 first, then the trans flags, then the strides.
+template <typename TIn, typename TOut>
+int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                 TOut alpha, const TIn* a, int64_t lda, int64_t stride_a, const TIn* b,
+                 int64_t ldb, int64_t stride_b, TOut beta, TOut* c, int64_t ldc,
+                 int64_t stride_c, int64_t batch, int batch_type) {
+  if (!hh) return SBAMD_INVALID_HANDLE;
+  Handle* h = &hh->impl;
+  if (m < 0 || n < 0 || k < 0 || batch < 0 || lda < 0 || ldb < 0 || ldc < 0) return SBAMD_INVALID_VALUE;
+  if (batch_type != SBAMD_BATCH_STRIDED && batch_type != SBAMD_BATCH_INTERLEAVED) return SBAMD_INVALID_VALUE;
+  DeviceGuard guard(h->device);
+  if (!guard.ok) return SBAMD_HIP_ERROR;
+  h->last_kernel = -1;
+
+  if (alpha == TOut(0)) {
+    // gemm_interface.hpp:112-139.  size_c == stride_c picks a whole-buffer
+    // scale; with ldc == m it is the vector _scal, whose zero factor stores
+    // zeros (blas1_interface.hpp:444-448); every other route is _scal_matrix,
+    // which multiplies (a factor of one launches nothing, :498-499).
+    if (m == 0 || n == 0 || batch == 0) return SBAMD_OK;
+    if (!c) return SBAMD_INVALID_VALUE;
+    const int64_t size_c = ldc * n;
+    hipError_t e = hipSuccess;
+    if (batch_type == SBAMD_BATCH_INTERLEAVED && batch > 1) {
+      // Interleaved items share every column: element (r, c) of item b sits
+      // at c*ldc*batch + r*batch + b, so the m x n windows of all items form
+      // one (m*batch) x n window with leading dimension ldc*batch.
+      if (!(beta == TOut(1))) e = scale_c<TOut>(h, c, m * batch, n, ldc * batch, 0, 1, beta, false);
+    } else if (size_c == stride_c) {
+      if (ldc == m) {
+        e = scale_c<TOut>(h, c, size_c * batch, 1, size_c * batch, 0, 1, beta, beta == TOut(0));
+      } else if (!(beta == TOut(1))) {
+        e = scale_c<TOut>(h, c, m, n * batch, ldc, 0, 1, beta, false);
+      }
+    } else if (!(beta == TOut(1))) {
+      e = scale_c<TOut>(h, c, m, n, ldc, stride_c, batch, beta, false);
+    }
+    return e == hipSuccess ? SBAMD_OK : fail_hip(h, e, "scale launch");
+  }
+
+  const char ta_c = char(std::tolower(static_cast<unsigned char>(transa)));
+  const char tb_c = char(std::tolower(static_cast<unsigned char>(transb)));
+  if (ta_c != 'n' && ta_c != 't' && ta_c != 'c') return SBAMD_INVALID_TRANSA;  // :144-145
+  if (tb_c != 'n' && tb_c != 't' && tb_c != 'c') return SBAMD_INVALID_TRANSB;  // :146-147
+  const bool ta = ta_c != 'n';
+  const bool tb = tb_c != 'n';
+
+  if (batch > 1 && batch_type == SBAMD_BATCH_STRIDED) {  // :158-166
+    const int64_t c_size = ldc * n;
+    if (stride_c < c_size || stride_c < 0) return SBAMD_INVALID_STRIDEC;
+    if (stride_a < 0) return SBAMD_INVALID_STRIDEA;
+    if (stride_b < 0) return SBAMD_INVALID_STRIDEB;
+  }
+
+  // Nothing to write: the reference launches work-groups that exit at once
+  // (src/operations/blas3/gemm_local.hpp:302, :596-598).
+  if (m == 0 || n == 0 || batch == 0) return SBAMD_OK;
+  if (!c || (k > 0 && (!a || !b))) return SBAMD_INVALID_VALUE;
+  if (batch_type == SBAMD_BATCH_INTERLEAVED && batch > 1) return SBAMD_NOT_SUPPORTED;
+
+  Problem<TIn, TOut> p;
+  p.ta = ta;
+  p.tb = tb;
+  p.m = m;
+  p.n = n;
+  p.k = k;
+  p.alpha = alpha;
+  p.beta = beta;
+  p.a = a;
+  p.lda = lda;
+  p.stride_a = stride_a;
+  p.b = b;
+  p.ldb = ldb;
+  p.stride_b = stride_b;
+  p.c = c;
+  p.ldc = ldc;
+  p.stride_c = stride_c;
+  p.batch = batch;
+  p.beta_zero = (beta == TOut(0));  // gemm_interface.hpp:92 (isZero)
+  hipError_t e = run_backend(h, p);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(h, e, "gemm launch");
+}
+
+// _gemm_batched's default strides (gemm_interface.hpp:213-219).
+template <typename TIn, typename TOut>
+int gemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                 TOut alpha, const TIn* a, int64_t lda, const TIn* b, int64_t ldb, TOut beta,
+                 TOut* c, int64_t ldc, int64_t batch, int batch_type) {
+  int64_t sa = 0, sb = 0, sc = 0;
+  if (batch_type == SBAMD_BATCH_STRIDED) {
+    sa = (std::tolower(static_cast<unsigned char>(transa)) != 'n') ? m * lda : k * lda;
+    sb = (std::tolower(static_cast<unsigned char>(transb)) != 'n') ? ldb * k : n * ldb;
+    sc = ldc * n;
+  }
+  return gemm_backend<TIn, TOut>(h, transa, transb, m, n, k, alpha, a, lda, sa, b, ldb, sb, beta, c,
+                                 ldc, sc, batch, batch_type);
+}
+
+}  // namespace
+}  // namespace sbamd
+
+using namespace sbamd;
+
+extern "C" {
+
+const char* sbamd_status_string(int status) {
+  switch (status) {
+    case SBAMD_OK: return "success";
+    case SBAMD_INVALID_TRANSA: return "invalid _TransA";
+    case SBAMD_INVALID_TRANSB: return "invalid _TransB";
+    case SBAMD_INVALID_STRIDEC: return "invalid _stridec";
+    case SBAMD_INVALID_STRIDEA: return "invalid _stridea";
+    case SBAMD_INVALID_STRIDEB: return "invalid _strideb";
+    case SBAMD_INVALID_HANDLE: return "invalid handle";
+    case SBAMD_INVALID_VALUE: return "invalid value";
+    case SBAMD_HIP_ERROR: return "HIP runtime error";
+    case SBAMD_ALLOC_FAILED: return "device allocation failed";
+    case SBAMD_NOT_SUPPORTED: return "not supported";
+    default: return "unknown status";
+  }
+}
+
+int sbamd_create(sbamd_handle_t* out, int device, void* stream) {
+  if (!out) return SBAMD_INVALID_VALUE;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return SBAMD_HIP_ERROR;
+  sbamd_handle_s* h = new (std::nothrow) sbamd_handle_s;
+  if (!h) return SBAMD_ALLOC_FAILED;
+  h->impl.device = device;
+  DeviceGuard guard(device);
+  hipDeviceProp_t prop;
+  if (!guard.ok || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete h;
+    return SBAMD_HIP_ERROR;
+  }
+  h->impl.compute_units = prop.multiProcessorCount;
+  if (stream) {
+    h->impl.stream = static_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&h->impl.stream, hipStreamNonBlocking) != hipSuccess) {
+      delete h;
+      return SBAMD_HIP_ERROR;
+    }
+    h->impl.owns_stream = true;
+  }
+  *out = h;
+  return SBAMD_OK;
+}
+
+int sbamd_destroy(sbamd_handle_t h) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  DeviceGuard guard(h->impl.device);
+  (void)hipStreamSynchronize(h->impl.stream);
+  if (h->impl.scratch) (void)hipFree(h->impl.scratch);
+  if (h->impl.owns_stream) (void)hipStreamDestroy(h->impl.stream);
+  delete h;
+  return SBAMD_OK;
+}
+
+int sbamd_wait(sbamd_handle_t h) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  hipError_t e = hipStreamSynchronize(h->impl.stream);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "stream synchronize");
+}
+
+int sbamd_get_num_compute_units(sbamd_handle_t h, int* out) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!out) return SBAMD_INVALID_VALUE;
+  *out = h->impl.compute_units;
+  return SBAMD_OK;
+}
+
+int sbamd_get_stream(sbamd_handle_t h, void** out_stream) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!out_stream) return SBAMD_INVALID_VALUE;
+  *out_stream = h->impl.stream;
+  return SBAMD_OK;
+}
+
+const char* sbamd_last_error(sbamd_handle_t h) { return h ? h->impl.last_error.c_str() : "invalid handle"; }
+
+int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (kernel < SBAMD_KERNEL_AUTO || kernel > SBAMD_KERNEL_HUGE || param < 0) return SBAMD_INVALID_VALUE;
+  h->impl.kernel_override = kernel;
+  h->impl.kernel_param = param;
+  return SBAMD_OK;
+}
+
+int sbamd_last_kernel(sbamd_handle_t h) { return h ? h->impl.last_kernel : -1; }
+
+int sbamd_event_record(sbamd_handle_t h, sbamd_event_t* out) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!out) return SBAMD_INVALID_VALUE;
+  DeviceGuard guard(h->impl.device);
+  sbamd_event_s* ev = new (std::nothrow) sbamd_event_s;
+  if (!ev) return SBAMD_ALLOC_FAILED;
+  hipError_t e = hipEventCreate(&ev->ev);
+  if (e == hipSuccess) e = hipEventRecord(ev->ev, h->impl.stream);
+  if (e != hipSuccess) {
+    delete ev;
+    return fail_hip(&h->impl, e, "event record");
+  }
+  *out = ev;
+  return SBAMD_OK;
+}
+
+int sbamd_stream_wait_event(sbamd_handle_t h, sbamd_event_t ev) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!ev) return SBAMD_INVALID_VALUE;
+  hipError_t e = hipStreamWaitEvent(h->impl.stream, ev->ev, 0);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "stream wait event");
+}
+
+int sbamd_event_synchronize(sbamd_event_t ev) {
+  if (!ev) return SBAMD_INVALID_VALUE;
+  return hipEventSynchronize(ev->ev) == hipSuccess ? SBAMD_OK : SBAMD_HIP_ERROR;
+}
+
+int sbamd_event_elapsed_ms(sbamd_event_t start, sbamd_event_t stop, float* ms) {
+  if (!start || !stop || !ms) return SBAMD_INVALID_VALUE;
+  return hipEventElapsedTime(ms, start->ev, stop->ev) == hipSuccess ? SBAMD_OK : SBAMD_HIP_ERROR;
+}
+
+int sbamd_event_destroy(sbamd_event_t ev) {
+  if (!ev) return SBAMD_INVALID_VALUE;
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return SBAMD_OK;
+}
+
+int sbamd_malloc(sbamd_handle_t h, void** out, size_t bytes) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!out) return SBAMD_INVALID_VALUE;
+  DeviceGuard guard(h->impl.device);
+  *out = nullptr;
+  hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "hipMalloc");
+}
+
+int sbamd_free(sbamd_handle_t h, void* ptr) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!ptr) return SBAMD_OK;
+  DeviceGuard guard(h->impl.device);
+  (void)hipStreamSynchronize(h->impl.stream);
+  hipError_t e = hipFree(ptr);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "hipFree");
+}
+
+int sbamd_copy_to_device(sbamd_handle_t h, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (bytes == 0) return SBAMD_OK;
+  if (!dst_dev || !src_host) return SBAMD_INVALID_VALUE;
+  hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->impl.stream);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "copy to device");
+}
+
+int sbamd_copy_to_host(sbamd_handle_t h, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (bytes == 0) return SBAMD_OK;
+  if (!dst_host || !src_dev) return SBAMD_INVALID_VALUE;
+  hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->impl.stream);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "copy to host");
+}
+
+int sbamd_memset(sbamd_handle_t h, void* dst_dev, int byte_value, size_t bytes) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (bytes == 0) return SBAMD_OK;
+  if (!dst_dev) return SBAMD_INVALID_VALUE;
+  hipError_t e = hipMemsetAsync(dst_dev, byte_value, bytes, h->impl.stream);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "memset");
+}
+
+int sbamd_fill_uniform(sbamd_handle_t h, void* dst_dev, int64_t count, int dtype, uint64_t seed,
+                       double lo, double hi) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (count < 0 || dtype < 0 || dtype > 3 || (count > 0 && !dst_dev)) return SBAMD_INVALID_VALUE;
+  DeviceGuard guard(h->impl.device);
+  hipError_t e = run_fill_uniform(&h->impl, dst_dev, count, dtype, seed, lo, hi);
+  return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "fill launch");
+}
+
+/* ------------------------------------------------------------ fp32 / fp64 */
+
+int sbamd_sgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                float alpha, const float* a, int64_t lda, const float* b, int64_t ldb, float beta,
+                float* c, int64_t ldc) {
+  // blas::_gemm: strides 0, batch 1, strided (gemm_interface.hpp:194-197)
+  return gemm_backend<float, float>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c,
+                                    ldc, 0, 1, SBAMD_BATCH_STRIDED);
+}
+
+int sbamd_dgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                double alpha, const double* a, int64_t lda, const double* b, int64_t ldb,
+                double beta, double* c, int64_t ldc) {
+  return gemm_backend<double, double>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta,
+                                      c, ldc, 0, 1, SBAMD_BATCH_STRIDED);
+}
+
+int sbamd_sgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                        float alpha, const float* a, int64_t lda, const float* b, int64_t ldb,
+                        float beta, float* c, int64_t ldc, int64_t batch, int batch_type) {
+  return gemm_batched<float, float>(h, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc,
+                                    batch, batch_type);
+}
+
+int sbamd_dgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                        double alpha, const double* a, int64_t lda, const double* b, int64_t ldb,
+                        double beta, double* c, int64_t ldc, int64_t batch, int batch_type) {
+  return gemm_batched<double, double>(h, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c,
+                                      ldc, batch, batch_type);
+}
+
+int sbamd_sgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                                int64_t k, float alpha, const float* a, int64_t lda,
+                                int64_t stride_a, const float* b, int64_t ldb, int64_t stride_b,
+                                float beta, float* c, int64_t ldc, int64_t stride_c,
+                                int64_t batch) {
+  return gemm_backend<float, float>(h, transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb,
+                                    stride_b, beta, c, ldc, stride_c, batch, SBAMD_BATCH_STRIDED);
+}
+
+int sbamd_dgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                                int64_t k, double alpha, const double* a, int64_t lda,
+                                int64_t stride_a, const double* b, int64_t ldb, int64_t stride_b,
+                                double beta, double* c, int64_t ldc, int64_t stride_c,
+                                int64_t batch) {
+  return gemm_backend<double, double>(h, transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb,
+                                      stride_b, beta, c, ldc, stride_c, batch, SBAMD_BATCH_STRIDED);
+}
+
+/* ------------------------------------------------- half / bfloat16 storage */
+
+int sbamd_hgemm(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float, const uint16_t*,
+                int64_t, const uint16_t*, int64_t, float, uint16_t*, int64_t) {
+  return SBAMD_NOT_SUPPORTED;
+}
+int sbamd_hsgemm(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float, const uint16_t*,
+                 int64_t, const uint16_t*, int64_t, float, float*, int64_t) {
+  return SBAMD_NOT_SUPPORTED;
+}
+int sbamd_bsgemm(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float, const uint16_t*,
+                 int64_t, const uint16_t*, int64_t, float, float*, int64_t) {
+  return SBAMD_NOT_SUPPORTED;
+}
+int sbamd_hgemm_strided_batched(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float,
+                                const uint16_t*, int64_t, int64_t, const uint16_t*, int64_t,
+                                int64_t, float, uint16_t*, int64_t, int64_t, int64_t) {
+  return SBAMD_NOT_SUPPORTED;
+}
+int sbamd_hsgemm_strided_batched(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float,
+                                 const uint16_t*, int64_t, int64_t, const uint16_t*, int64_t,
+                                 int64_t, float, float*, int64_t, int64_t, int64_t) {
+  return SBAMD_NOT_SUPPORTED;
+}
+int sbamd_bsgemm_strided_batched(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float,
+                                 const uint16_t*, int64_t, int64_t, const uint16_t*, int64_t,
+                                 int64_t, float, float*, int64_t, int64_t, int64_t) {
+  return SBAMD_NOT_SUPPORTED;
+}
+
+}  // extern "C"

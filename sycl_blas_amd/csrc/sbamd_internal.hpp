@@ -1,0 +1,68 @@
+// Internal declarations shared by the C-ABI translation unit and the kernel
+// translation units (one per storage type, so they compile in parallel).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/sbamd_gemm.h"
+
+namespace sbamd {
+
+struct Handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  int compute_units = 0;
+  int kernel_override = SBAMD_KERNEL_AUTO;
+  int kernel_param = 0;
+  int last_kernel = -1;
+  // Scratch for the split-K cube (the reference draws it from
+  // Temp_Mem_Pool / acquire_temp_mem, src/sb_handle/portblas_handle.hpp:42-101).
+  // Grown on demand, reused across calls, freed with the handle.  Work on one
+  // stream is ordered, so consecutive calls may share it.
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  std::mutex mu;
+  std::string last_error;
+};
+
+// Everything the front end has already validated and normalised.
+template <typename TIn, typename TOut>
+struct Problem {
+  bool ta, tb;  // op(A) / op(B) transposed
+  int64_t m, n, k;
+  TOut alpha, beta;
+  const TIn* a;
+  int64_t lda, stride_a;
+  const TIn* b;
+  int64_t ldb, stride_b;
+  TOut* c;
+  int64_t ldc, stride_c;
+  int64_t batch;
+  bool beta_zero;
+};
+
+// Per-type back ends (defined in gemm_f32.hip, gemm_f64.hip, gemm_half.hip).
+// Each picks a kernel family (or obeys h->kernel_override), launches on
+// h->stream, records h->last_kernel and returns a HIP error code.
+hipError_t run_gemm_f32(Handle* h, const Problem<float, float>& p);
+hipError_t run_gemm_f64(Handle* h, const Problem<double, double>& p);
+
+// C = beta * C over `batch` windows of rows x cols (alpha == 0 path).
+hipError_t run_scale_f32(Handle* h, float* c, int64_t rows, int64_t cols, int64_t ld,
+                         int64_t stride, int64_t batch, float beta, bool assign_zero);
+hipError_t run_scale_f64(Handle* h, double* c, int64_t rows, int64_t cols, int64_t ld,
+                         int64_t stride, int64_t batch, double beta, bool assign_zero);
+
+// Device-side uniform fill (dtype codes as in sbamd_fill_uniform).
+hipError_t run_fill_uniform(Handle* h, void* dst, int64_t count, int dtype, uint64_t seed,
+                            double lo, double hi);
+
+// Grow the handle's scratch buffer to at least `bytes`.
+hipError_t ensure_scratch(Handle* h, size_t bytes);
+
+}  // namespace sbamd
