@@ -25,6 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Pointers into LDS carry their address space so every access is a ds_*
+// instruction (a generic pointer would fall back to flat loads).
+#define SBAMD_LDS __attribute__((address_space(3)))
+
 // Arguments shared by every kernel in this file.  Pointers are typed in the
 // kernels; sizes are 64-bit so 65536 x 65536 operands index correctly.
 template <typename T>
@@ -68,7 +72,8 @@ struct Mfma<float> {
   __device__ static inline int acc_i(int r, int lane) {
     return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
   }
-  static constexpr int PAD = 4;  // LDS row = BMN + PAD elements
+  static constexpr int GS = 2;      // MFMA k-steps served by one fragment fetch
+  static constexpr int PAD_MN = 0;  // [k][mn] image: 32 consecutive lanes, 32 consecutive banks
 };
 
 // v_mfma_f64_16x16x4_f64: lane l feeds op0[i = l & 15][k = l >> 4] and
@@ -88,9 +93,11 @@ struct Mfma<double> {
   __device__ static inline int lane_mn(int lane) { return lane & 15; }
   __device__ static inline int lane_k(int lane) { return lane >> 4; }
   __device__ static inline int acc_i(int r, int lane) { return (lane >> 4) + 4 * r; }
-  // Row stride = 16 (mod 32) doubles: the 16 lanes of k and the 16 lanes of
-  // k + 1 in one ds_read_b64 lane group land on disjoint halves of the 64 banks.
-  static constexpr int PAD = 16;
+  static constexpr int GS = 1;
+  // [k][mn] image: row stride = 16 (mod 32) doubles, so the 16 lanes of k and
+  // the 16 lanes of k + 1 in one ds_read_b64 lane group land on disjoint
+  // halves of the 64 banks.
+  static constexpr int PAD_MN = 16;
 };
 
 // ------------------------------------------------------------- tile loading
@@ -98,71 +105,113 @@ struct Mfma<double> {
 // An operand tile covers BMN indices along M (or N) and BK along K.
 // KMAJOR = the K index is the contiguous one in global memory
 //          (A with trans != 'n', B with trans == 'n').
-// Each thread moves NV 16-byte vectors per tile: global -> registers ->
-// LDS image [BK][BMN + PAD].
+// Each thread moves NV 16-byte vectors per tile: global -> registers -> LDS.
+//
+// LDS images (chosen so that neither the store nor the fragment read
+// transposes or conflicts):
+//   MN-major operand: [BK][BMN + PAD_MN]; a fragment is one 4/8-byte read per
+//     lane and k-step, consecutive lanes on consecutive banks.
+//   K-major operand:  [BMN][BK + 2], k fastest as in global memory.  The odd
+//     multiple of 8 bytes in the row stride spreads the lanes of a fragment
+//     read over all banks.  For fp32 every aligned group of four k is stored
+//     as (k0, k2, k1, k3), so lane-half h reads the 8 bytes (k = 4j + h,
+//     k = 4j + 2 + h): exactly its operands for MFMA steps 2j and 2j + 1.
 template <typename T, int BMN, int BK, int NT, bool KMAJOR>
 struct TileLoader {
   using M = Mfma<T>;
   static constexpr int V = M::V;
-  static constexpr int S = BMN + M::PAD;
+  static constexpr int S = KMAJOR ? (BK + 2) : (BMN + M::PAD_MN);  // LDS row stride (elements)
+  static constexpr int ELEMS = KMAJOR ? BMN * S : BK * S;
   static constexpr int NVEC = BMN * BK / V;
   static_assert(NVEC % NT == 0, "tile must split evenly over the workgroup");
+  static_assert(BK % 4 == 0, "K step is handled in groups of four");
   static constexpr int NV = NVEC / NT;
   static constexpr int PER_ROW = KMAJOR ? (BK / V) : (BMN / V);
 
   T reg[NV][V];
 
-  // mn0: first M/N index of the tile, mn_lim: matrix extent along M/N,
-  // k0: first k of the tile, k_end: end of this workgroup's K range.
-  // fast: the tile is interior, fully inside K, and 16-byte loads are legal.
-  __device__ inline void load(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim,
-                              int64_t k0, int64_t k_end, bool fast, int tid) {
+  // Interior tile, whole K step, 16-byte aligned: straight-line vector loads.
+  __device__ inline void load_fast(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t k0,
+                                   int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
-      // KMAJOR: row walks mn, col walks k.  Otherwise row walks k, col mn.
-      const int64_t mn = mn0 + (KMAJOR ? row : col);
-      const int64_t kk = k0 + (KMAJOR ? col : row);
-      if (fast) {
-        const T* p = KMAJOR ? (x + kk + mn * ld) : (x + mn + kk * ld);
-        const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(p);
+      const T* p = KMAJOR ? (x + (k0 + col) + (mn0 + row) * ld) : (x + (mn0 + col) + (k0 + row) * ld);
+      const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(p);
 #pragma unroll
-        for (int e = 0; e < V; ++e) reg[i][e] = vv[e];
-      } else {
+      for (int e = 0; e < V; ++e) reg[i][e] = vv[e];
+    }
+  }
+
+  // Edge tile, K tail or unaligned operand: element loads.  Rows/columns past
+  // the matrix edge re-read the last valid one (they only feed C elements that
+  // are never stored); k past the end contributes exactly zero.
+  __device__ inline void load_edge(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim,
+                                   int64_t k0, int64_t k_end, int tid) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          int64_t mne = KMAJOR ? mn : (mn + e);
-          const int64_t ke = KMAJOR ? (kk + e) : kk;
-          // Rows/columns past the matrix edge re-read the last valid one: they
-          // only feed C elements that are never stored.  k past the end must
-          // contribute exactly zero.
-          mne = mne < mn_lim ? mne : (mn_lim - 1);
-          T val = T(0);
-          if (ke < k_end) val = KMAJOR ? x[ke + mne * ld] : x[mne + ke * ld];
-          reg[i][e] = val;
-        }
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / PER_ROW;
+      const int col = (v % PER_ROW) * V;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        int64_t mn = mn0 + (KMAJOR ? row : col + e);
+        const int64_t kk = k0 + (KMAJOR ? col + e : row);
+        mn = mn < mn_lim ? mn : (mn_lim - 1);
+        const bool live = kk < k_end;
+        const int64_t ks = live ? kk : (k_end - 1);  // k_end > k0 >= 0 here
+        const T val = KMAJOR ? x[ks + mn * ld] : x[mn + ks * ld];
+        reg[i][e] = live ? val : T(0);
       }
     }
   }
 
-  __device__ inline void store(T* __restrict__ lds, int tid) const {
+  __device__ inline void store(SBAMD_LDS T* lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
-      if (KMAJOR) {
-        // transpose on the way in: V scalar stores down a column of the image
-#pragma unroll
-        for (int e = 0; e < V; ++e) lds[(col + e) * S + row] = reg[i][e];
+      SBAMD_LDS T* p = lds + row * S + col;
+      if (KMAJOR && V == 4) {
+        // (k0, k2, k1, k3): two 8-byte stores (the row stride is only 8-byte aligned)
+        typedef T pair_t __attribute__((ext_vector_type(2)));
+        pair_t lo, hi;
+        lo[0] = reg[i][0];
+        lo[1] = reg[i][2];
+        hi[0] = reg[i][1];
+        hi[1] = reg[i][3];
+        *reinterpret_cast<SBAMD_LDS pair_t*>(p) = lo;
+        *reinterpret_cast<SBAMD_LDS pair_t*>(p + 2) = hi;
       } else {
         typename M::vec_t vv;
 #pragma unroll
         for (int e = 0; e < V; ++e) vv[e] = reg[i][e];
-        *reinterpret_cast<typename M::vec_t*>(lds + row * S + col) = vv;
+        *reinterpret_cast<SBAMD_LDS typename M::vec_t*>(p) = vv;
       }
+    }
+  }
+
+  // Fragments of one lane for the GS consecutive MFMA k-steps of group `grp`
+  // (GS = 2 for fp32, 1 for fp64): out[e] belongs to step grp*GS + e.
+  // `mn` is the lane's M/N index inside the tile.
+  __device__ static inline void fragment(const SBAMD_LDS T* lds, int grp, int mn, int lane,
+                                         T (&out)[M::GS]) {
+    const int lk = M::lane_k(lane);
+    if (KMAJOR) {
+      if (M::GS == 2) {
+        typedef T pair_t __attribute__((ext_vector_type(2)));
+        const pair_t pv = *reinterpret_cast<const SBAMD_LDS pair_t*>(lds + mn * S + 4 * grp + 2 * lk);
+        out[0] = pv[0];
+        out[M::GS - 1] = pv[1];
+      } else {
+        out[0] = lds[mn * S + M::TK * grp + lk];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < M::GS; ++e) out[e] = lds[((grp * M::GS + e) * M::TK + lk) * S + mn];
     }
   }
 };
@@ -200,16 +249,126 @@ struct GemmTile {
   static constexpr int MI = WTM / M::T;
   static constexpr int NI = WTN / M::T;
   static_assert(MI >= 1 && NI >= 1, "wave tile smaller than one MFMA");
-  static_assert(BK % M::TK == 0, "BK must hold whole MFMA k-steps");
+  static constexpr int NGRP = BK / (M::TK * M::GS);
+  static_assert(BK % (M::TK * M::GS) == 0, "BK must hold whole fragment groups");
   // A is K-major when transposed; B is K-major when NOT transposed.
   using LoadA = TileLoader<T, BM, BK, NT, TA>;
   using LoadB = TileLoader<T, BN, BK, NT, !TB>;
-  static constexpr int SA = LoadA::S;
-  static constexpr int SB = LoadB::S;
-  static constexpr int A_ELEMS = BK * SA;
-  static constexpr int B_ELEMS = BK * SB;
+  static constexpr int A_ELEMS = (LoadA::ELEMS + 3) & ~3;  // keep B 16-byte aligned
+  static constexpr int B_ELEMS = (LoadB::ELEMS + 3) & ~3;
   static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
   static constexpr size_t LDS_BYTES = 2 * size_t(STAGE_ELEMS) * sizeof(T);
+};
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+struct GemmBody {
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
+  using M = Mfma<T>;
+  using LoadA = typename K::LoadA;
+  using LoadB = typename K::LoadB;
+
+  typename M::acc_t acc[K::MI][K::NI];
+  LoadA la;
+  LoadB lb;
+
+  // All MFMAs of one K step.  The fragments of group g + 1 are fetched while
+  // the matrix instructions of group g run: the source is software-pipelined
+  // and the sched_group_barrier sequence pins the interleave (one LDS read
+  // slot behind each MFMA), because the scheduler otherwise sinks every read
+  // next to its first use and exposes the LDS latency once per group.
+  template <int NVMEM>
+  __device__ inline void compute(const SBAMD_LDS T* as, const SBAMD_LDS T* bs, int a_mn,
+                                 int b_mn, int lane) {
+    constexpr int NM = K::MI * K::NI * M::GS;  // MFMAs per group
+    T fa[2][K::MI][M::GS], fb[2][K::NI][M::GS];
+#pragma unroll
+    for (int i = 0; i < K::MI; ++i) LoadA::fragment(as, 0, a_mn + i * M::T, lane, fa[0][i]);
+#pragma unroll
+    for (int j = 0; j < K::NI; ++j) LoadB::fragment(bs, 0, b_mn + j * M::T, lane, fb[0][j]);
+#pragma unroll
+    for (int grp = 0; grp < K::NGRP; ++grp) {
+      const int cur = grp & 1, nxt = cur ^ 1;
+      if (grp + 1 < K::NGRP) {
+#pragma unroll
+        for (int i = 0; i < K::MI; ++i) LoadA::fragment(as, grp + 1, a_mn + i * M::T, lane, fa[nxt][i]);
+#pragma unroll
+        for (int j = 0; j < K::NI; ++j) LoadB::fragment(bs, grp + 1, b_mn + j * M::T, lane, fb[nxt][j]);
+      }
+#pragma unroll
+      for (int e = 0; e < M::GS; ++e)
+#pragma unroll
+        for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+          for (int j = 0; j < K::NI; ++j)
+            // op0 carries the N index and op1 the M index, so a lane ends up
+            // holding one M index (contiguous in column-major C).
+            acc[i][j] = M::mma(fb[cur][j][e], fa[cur][i][e], acc[i][j]);
+    }
+    // Desired order (0x008 = MFMA, 0x020 = VMEM read, 0x100 = DS read): the
+    // first group's fragments; then behind each MFMA one of the NVMEM global
+    // loads of the next tile (issued early so they land before the LDS store
+    // at the end of the step), and behind every STRIDE-th MFMA one fragment
+    // read, which keeps the reads about one group ahead of their use.
+    constexpr int SLOTS = K::MI + K::NI;  // fragment reads per group after pairing
+    constexpr int STRIDE = NM / SLOTS > 0 ? NM / SLOTS : 1;
+    constexpr int PER = SLOTS / NM > 0 ? SLOTS / NM : 1;
+    __builtin_amdgcn_sched_group_barrier(0x100, SLOTS, 0);
+#pragma unroll
+    for (int n = 0; n < K::NGRP * NM; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (n < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (n % STRIDE == 0) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+    }
+  }
+
+  // FAST: this workgroup's tile is interior and both operands allow 16-byte
+  // loads; whole K steps then use load_fast, only a K tail uses load_edge.
+  template <bool FAST>
+  __device__ inline void run(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
+                             int64_t k_begin, int64_t k_end, SBAMD_LDS T* smem, int tid, int a_mn,
+                             int b_mn) {
+    const int lane = tid & 63;
+    const int64_t klen = k_end > k_begin ? k_end - k_begin : 0;
+    const int nfull = FAST ? int(klen / BK) : 0;
+    const int nk = int((klen + BK - 1) / BK);
+    if (nk == 0) return;
+
+    if (FAST && nfull > 0) {
+      la.load_fast(a, g.lda, m0, k_begin, tid);
+      lb.load_fast(b, g.ldb, n0, k_begin, tid);
+    } else {
+      la.load_edge(a, g.lda, m0, g.m, k_begin, k_end, tid);
+      lb.load_edge(b, g.ldb, n0, g.n, k_begin, k_end, tid);
+    }
+    la.store(smem, tid);
+    lb.store(smem + K::A_ELEMS, tid);
+    __syncthreads();
+
+    int kt = 0;
+    if (FAST) {
+      // steady state: the next tile is a whole K step
+      for (; kt + 1 < nfull; ++kt) {
+        const int64_t k0 = k_begin + int64_t(kt + 1) * BK;
+        la.load_fast(a, g.lda, m0, k0, tid);
+        lb.load_fast(b, g.ldb, n0, k0, tid);
+        compute<LoadA::NV + LoadB::NV>(smem + (kt & 1) * K::STAGE_ELEMS, smem + (kt & 1) * K::STAGE_ELEMS + K::A_ELEMS, a_mn, b_mn, lane);
+        la.store(smem + ((kt + 1) & 1) * K::STAGE_ELEMS, tid);
+        lb.store(smem + ((kt + 1) & 1) * K::STAGE_ELEMS + K::A_ELEMS, tid);
+        __syncthreads();
+      }
+    }
+    // remaining tiles (all of them when !FAST; at most the K tail when FAST)
+    for (; kt + 1 < nk; ++kt) {
+      const int64_t k0 = k_begin + int64_t(kt + 1) * BK;
+      la.load_edge(a, g.lda, m0, g.m, k0, k_end, tid);
+      lb.load_edge(b, g.ldb, n0, g.n, k0, k_end, tid);
+      compute<0>(smem + (kt & 1) * K::STAGE_ELEMS, smem + (kt & 1) * K::STAGE_ELEMS + K::A_ELEMS, a_mn, b_mn, lane);
+      la.store(smem + ((kt + 1) & 1) * K::STAGE_ELEMS, tid);
+      lb.store(smem + ((kt + 1) & 1) * K::STAGE_ELEMS + K::A_ELEMS, tid);
+      __syncthreads();
+    }
+    compute<0>(smem + (kt & 1) * K::STAGE_ELEMS, smem + (kt & 1) * K::STAGE_ELEMS + K::A_ELEMS, a_mn, b_mn, lane);
+  }
 };
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
@@ -218,7 +377,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
   using M = Mfma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
+  SBAMD_LDS T* smem = (SBAMD_LDS T*)smem_raw;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -249,70 +408,22 @@ __global__ void __launch_bounds__(WM* WN * 64)
     c += int64_t(z) * g.stride_c;
   }
 
-  const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
-  const bool fast_a = interior && g.vec_a;
-  const bool fast_b = interior && g.vec_b;
-
-  typename M::acc_t acc[K::MI][K::NI];
+  GemmBody<T, BM, BN, BK, WM, WN, TA, TB> body;
 #pragma unroll
   for (int i = 0; i < K::MI; ++i)
 #pragma unroll
     for (int j = 0; j < K::NI; ++j)
 #pragma unroll
-      for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = T(0);
-
-  typename K::LoadA la;
-  typename K::LoadB lb;
-
-  const int64_t klen = k_end > k_begin ? k_end - k_begin : 0;
-  const int nk = int((klen + BK - 1) / BK);
-
-  if (nk > 0) {
-    const bool full0 = k_begin + BK <= k_end;
-    la.load(a, g.lda, m0, g.m, k_begin, k_end, fast_a && full0, tid);
-    lb.load(b, g.ldb, n0, g.n, k_begin, k_end, fast_b && full0, tid);
-    la.store(smem, tid);
-    lb.store(smem + K::A_ELEMS, tid);
-  }
-  __syncthreads();
+      for (int r = 0; r < M::NACC; ++r) body.acc[i][j][r] = T(0);
 
   const int frag_mn = M::lane_mn(lane);
-  const int frag_k = M::lane_k(lane);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const T* as = smem + cur * K::STAGE_ELEMS;
-    const T* bs = as + K::A_ELEMS;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      const int64_t k0 = k_begin + int64_t(kt + 1) * BK;
-      const bool full = k0 + BK <= k_end;
-      la.load(a, g.lda, m0, g.m, k0, k_end, fast_a && full, tid);
-      lb.load(b, g.ldb, n0, g.n, k0, k_end, fast_b && full, tid);
-    }
-
-#pragma unroll
-    for (int s = 0; s < BK / M::TK; ++s) {
-      const int kl = s * M::TK + frag_k;
-      T fa[K::MI], fb[K::NI];
-#pragma unroll
-      for (int i = 0; i < K::MI; ++i) fa[i] = as[kl * K::SA + wm * K::WTM + i * M::T + frag_mn];
-#pragma unroll
-      for (int j = 0; j < K::NI; ++j) fb[j] = bs[kl * K::SB + wn * K::WTN + j * M::T + frag_mn];
-      // op0 carries the N index and op1 the M index, so each lane ends up
-      // holding one M index (contiguous in column-major C) across its lanes.
-#pragma unroll
-      for (int i = 0; i < K::MI; ++i)
-#pragma unroll
-        for (int j = 0; j < K::NI; ++j) acc[i][j] = M::mma(fb[j], fa[i], acc[i][j]);
-    }
-
-    if (more) {
-      T* nxt = smem + (cur ^ 1) * K::STAGE_ELEMS;
-      la.store(nxt, tid);
-      lb.store(nxt + K::A_ELEMS, tid);
-    }
-    __syncthreads();
+  const int a_mn = wm * K::WTM + frag_mn;
+  const int b_mn = wn * K::WTN + frag_mn;
+  const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
+  if (interior && g.vec_a && g.vec_b) {
+    body.template run<true>(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
+  } else {
+    body.template run<false>(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
   }
 
   // ---- epilogue: C = alpha * acc (+ beta * C); products and the sum round
@@ -321,7 +432,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
   const bool read_c = !g.beta_zero && g.split_k <= 1;
 #pragma unroll
   for (int i = 0; i < K::MI; ++i) {
-    const int64_t mm = m0 + wm * K::WTM + i * M::T + frag_mn;
+    const int64_t mm = m0 + a_mn + i * M::T;
 #pragma unroll
     for (int j = 0; j < K::NI; ++j) {
 #pragma unroll
@@ -329,7 +440,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
         const int64_t nn = n0 + wn * K::WTN + j * M::T + M::acc_i(r, lane);
         if (mm < g.m && nn < g.n) {
           T* p = c + mm + nn * g.ldc;
-          T out = alpha * acc[i][j][r];
+          T out = alpha * body.acc[i][j][r];
           if (read_c) {
             const T bc = beta * (*p);
             out = out + bc;
