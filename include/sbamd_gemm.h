@@ -59,7 +59,8 @@ enum {
   SBAMD_KERNEL_SMALL = 2,    /* 64x64 macro tile (batched / small shapes)  */
   SBAMD_KERNEL_SPLITK = 3,   /* tall-skinny: K slabs -> cube -> reduction  */
   SBAMD_KERNEL_NAIVE = 4,    /* one thread per C element, sequential k     */
-  SBAMD_KERNEL_HUGE = 5      /* 256x128 macro tile                         */
+  SBAMD_KERNEL_HUGE = 5,     /* 256x128 macro tile                         */
+  SBAMD_KERNEL_INTERLEAVED = 6 /* batch-contiguous layout; reported, not pinnable */
 };
 
 typedef struct sbamd_handle_s* sbamd_handle_t;
@@ -96,6 +97,13 @@ int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param);
 /* Which family the last GEMM call on this handle launched (SBAMD_KERNEL_*),
  * -1 when it launched none (alpha == 0, empty problem). */
 int sbamd_last_kernel(sbamd_handle_t h);
+
+/* How the last split-K call cut K: `depth` slabs of `k_chunk` (the last one may
+ * be shorter).  depth == 1 when the last call did not split.  The cut decides
+ * the rounding of a split-K result (the reference's cut depends on the device's
+ * compute-unit count the same way, gemm_partial_local.hpp:174, :191-199), so a
+ * checker needs it to reproduce the result exactly. */
+int sbamd_last_splitk(sbamd_handle_t h, int64_t* depth, int64_t* k_chunk);
 
 /* ------------------------------------------------------------------ events */
 

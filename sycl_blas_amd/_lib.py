@@ -17,6 +17,7 @@ INVALID_TRANSA, INVALID_TRANSB, INVALID_STRIDEC, INVALID_STRIDEA, INVALID_STRIDE
 INVALID_HANDLE, INVALID_VALUE, HIP_ERROR, ALLOC_FAILED, NOT_SUPPORTED = 6, 7, 8, 9, 10
 BATCH_STRIDED, BATCH_INTERLEAVED = 0, 1
 KERNEL_AUTO, KERNEL_LARGE, KERNEL_SMALL, KERNEL_SPLITK, KERNEL_NAIVE, KERNEL_HUGE = 0, 1, 2, 3, 4, 5
+KERNEL_INTERLEAVED = 6
 
 _i64, _int, _f32, _f64, _vp, _ch = C.c_int64, C.c_int, C.c_float, C.c_double, C.c_void_p, C.c_char
 
@@ -45,6 +46,7 @@ SIGNATURES = {
     "sbamd_last_error": (C.c_char_p, [_vp]),
     "sbamd_set_kernel": (_int, [_vp, _int, _int]),
     "sbamd_last_kernel": (_int, [_vp]),
+    "sbamd_last_splitk": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sbamd_event_record": (_int, [_vp, C.POINTER(_vp)]),
     "sbamd_stream_wait_event": (_int, [_vp, _vp]),
     "sbamd_event_synchronize": (_int, [_vp]),

@@ -56,6 +56,22 @@ hipError_t launch_tile(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
 }
 
 template <typename T>
+hipError_t launch_interleaved(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream) {
+  constexpr int IR = 4, IC = 4;
+  const int64_t total = ceil_div(g.m, IR) * ceil_div(g.n, IC) * g.batch;
+  const int64_t grid = ceil_div(total, 256);
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (ta) {
+    if (tb) hipLaunchKernelGGL((gemm_interleaved_kernel<T, true, true, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_interleaved_kernel<T, true, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  } else {
+    if (tb) hipLaunchKernelGGL((gemm_interleaved_kernel<T, false, true, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_interleaved_kernel<T, false, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
 hipError_t launch_naive(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream) {
   const int64_t total = g.m * g.n * g.batch;
   const int64_t grid = ceil_div(total, 256);
@@ -115,6 +131,12 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   g.beta = p.beta;
   g.beta_zero = p.beta_zero ? 1 : 0;
 
+  if (p.interleaved) {
+    // First branch of the reference's dispatch (amd_gpu.hpp:58-74).
+    h->last_kernel = SBAMD_KERNEL_INTERLEAVED;
+    return launch_interleaved<T>(g, p.ta, p.tb, h->stream);
+  }
+
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
 
   int family = h->kernel_override;
@@ -163,6 +185,8 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
                          static_cast<const T*>(h->scratch), slice, int(depth), p.c, p.m, p.n,
                          p.ldc, p.beta, g.beta_zero);
       h->last_kernel = SBAMD_KERNEL_SPLITK;
+      h->last_depth = depth;
+      h->last_k_chunk = k_chunk;
       return hipGetLastError();
     }
     family = big ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;

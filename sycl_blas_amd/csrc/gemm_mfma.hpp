@@ -507,6 +507,67 @@ __global__ void __launch_bounds__(256) gemm_naive_kernel(const GemmArgs<T> g) {
   *p = out;
 }
 
+// ------------------------------------------------- interleaved batched GEMM
+// Element (r, c) of batch item b lives at (r + c*ld)*batch + b, so the batch
+// index is the contiguous one (test/unittest/blas3/blas3_gemm_common.hpp:54-69).
+// Consecutive lanes take consecutive batch items -- every access is coalesced
+// with no staging -- and each thread keeps an IR x IC register block of its
+// item's C, walking k in order.  Counterpart of the reference's
+// Gemm<..., interleaved> (src/operations/blas3/gemm_interleaved.hpp:104-537),
+// which likewise vectorises over the batch and uses no local memory.
+template <typename T, bool TA, bool TB, int IR, int IC>
+__global__ void __launch_bounds__(256) gemm_interleaved_kernel(const GemmArgs<T> g) {
+  const int64_t nb = g.batch;
+  const int64_t tiles_r = (g.m + IR - 1) / IR;
+  const int64_t tiles_c = (g.n + IC - 1) / IC;
+  const int64_t gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= nb * tiles_r * tiles_c) return;
+  const int64_t b = gid % nb;
+  const int64_t t = gid / nb;
+  const int64_t r0 = (t % tiles_r) * IR;
+  const int64_t c0 = (t / tiles_r) * IC;
+
+  T acc[IR][IC];
+#pragma unroll
+  for (int i = 0; i < IR; ++i)
+#pragma unroll
+    for (int j = 0; j < IC; ++j) acc[i][j] = T(0);
+
+  for (int64_t k = 0; k < g.k; ++k) {
+    T av[IR], bv[IC];
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      const int64_t r = r0 + i < g.m ? r0 + i : g.m - 1;  // clamped rows feed unstored elements only
+      av[i] = g.a[(TA ? (k + r * g.lda) : (r + k * g.lda)) * nb + b];
+    }
+#pragma unroll
+    for (int j = 0; j < IC; ++j) {
+      const int64_t c = c0 + j < g.n ? c0 + j : g.n - 1;
+      bv[j] = g.b[(TB ? (c + k * g.ldb) : (k + c * g.ldb)) * nb + b];
+    }
+#pragma unroll
+    for (int i = 0; i < IR; ++i)
+#pragma unroll
+      for (int j = 0; j < IC; ++j) acc[i][j] = fma_rn(av[i], bv[j], acc[i][j]);
+  }
+
+#pragma unroll
+  for (int j = 0; j < IC; ++j) {
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      if (r0 + i < g.m && c0 + j < g.n) {
+        T* p = g.c + ((r0 + i) + (c0 + j) * g.ldc) * nb + b;
+        T out = g.alpha * acc[i][j];
+        if (!g.beta_zero) {
+          const T bc = g.beta * (*p);
+          out = out + bc;
+        }
+        *p = out;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- C = beta*C
 // alpha == 0 path (src/interface/gemm_interface.hpp:112-139).  assign_zero is
 // the whole-vector _scal with a zero factor, which stores zeros

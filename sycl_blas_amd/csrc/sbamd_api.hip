@@ -87,6 +87,8 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   DeviceGuard guard(h->device);
   if (!guard.ok) return SBAMD_HIP_ERROR;
   h->last_kernel = -1;
+  h->last_depth = 1;
+  h->last_k_chunk = k;
 
   if (alpha == TOut(0)) {
     // gemm_interface.hpp:112-139.  size_c == stride_c picks a whole-buffer
@@ -132,7 +134,6 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   // (src/operations/blas3/gemm_local.hpp:302, :596-598).
   if (m == 0 || n == 0 || batch == 0) return SBAMD_OK;
   if (!c || (k > 0 && (!a || !b))) return SBAMD_INVALID_VALUE;
-  if (batch_type == SBAMD_BATCH_INTERLEAVED && batch > 1) return SBAMD_NOT_SUPPORTED;
 
   Problem<TIn, TOut> p;
   p.ta = ta;
@@ -153,6 +154,8 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   p.stride_c = stride_c;
   p.batch = batch;
   p.beta_zero = (beta == TOut(0));  // gemm_interface.hpp:92 (isZero)
+  // One item has the same addresses in both layouts, so it takes the strided kernels.
+  p.interleaved = batch_type == SBAMD_BATCH_INTERLEAVED && batch > 1;
   hipError_t e = run_backend(h, p);
   return e == hipSuccess ? SBAMD_OK : fail_hip(h, e, "gemm launch");
 }
@@ -265,6 +268,14 @@ int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param) {
 }
 
 int sbamd_last_kernel(sbamd_handle_t h) { return h ? h->impl.last_kernel : -1; }
+
+int sbamd_last_splitk(sbamd_handle_t h, int64_t* depth, int64_t* k_chunk) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!depth || !k_chunk) return SBAMD_INVALID_VALUE;
+  *depth = h->impl.last_depth;
+  *k_chunk = h->impl.last_k_chunk;
+  return SBAMD_OK;
+}
 
 int sbamd_event_record(sbamd_handle_t h, sbamd_event_t* out) {
   if (!h) return SBAMD_INVALID_HANDLE;

@@ -20,6 +20,8 @@ struct Handle {
   int kernel_override = SBAMD_KERNEL_AUTO;
   int kernel_param = 0;
   int last_kernel = -1;
+  int64_t last_depth = 1;    // split-K cut of the last call
+  int64_t last_k_chunk = 0;
   // Scratch for the split-K cube (the reference draws it from
   // Temp_Mem_Pool / acquire_temp_mem, src/sb_handle/portblas_handle.hpp:42-101).
   // Grown on demand, reused across calls, freed with the handle.  Work on one
@@ -44,6 +46,7 @@ struct Problem {
   int64_t ldc, stride_c;
   int64_t batch;
   bool beta_zero;
+  bool interleaved;  // batch index contiguous (gemm_batch_type_t::interleaved)
 };
 
 // Per-type back ends (defined in gemm_f32.hip, gemm_f64.hip, gemm_half.hip).

@@ -202,6 +202,12 @@ class SB_Handle:
     def last_kernel(self):
         return _lib.load().sbamd_last_kernel(self._h)
 
+    def last_splitk(self):
+        """(depth, k_chunk) of the last call's split-K cut; depth 1 = not split."""
+        depth, chunk = C.c_int64(), C.c_int64()
+        _check(self, _lib.load().sbamd_last_splitk(self._h, C.byref(depth), C.byref(chunk)))
+        return depth.value, chunk.value
+
 
 class helper:
     """blas::helper allocation and copy routines (include/portblas_helper.h)."""

@@ -109,7 +109,7 @@ def assert_reference_predicate(got, ref, what):
 
 
 def verify_gemm(h, dtype, offset, batch, m, n, k, transa, transb, alpha, beta, lda_mul, ldb_mul,
-                ldc_mul, batch_type=strided, form=oracle.FORM_REF, depth=1, k_chunk=0, exact=True):
+                ldc_mul, batch_type=strided, exact=True):
     """blas3_gemm_common.hpp:96-230 with the GPU in place of portBLAS."""
     rng = seeded(np.dtype(dtype).name, offset, batch, m, n, k, transa, transb, alpha, beta, lda_mul,
                  ldb_mul, ldc_mul, int(batch_type))
@@ -120,17 +120,6 @@ def verify_gemm(h, dtype, offset, batch, m, n, k, transa, transb, alpha, beta, l
     a_m = fill_random(rng, batch * size_a + offset, dtype)
     b_m = fill_random(rng, batch * size_b + offset, dtype)
     c_m = fill_random(rng, batch * size_c + offset, dtype)
-
-    # ground truth 1: the oracle (bitwise); ground truth 2: OpenBLAS (predicate)
-    c_orc = c_m.copy()
-    st = oracle.gemm_backend(transa, transb, m, n, k, alpha, a_m, lda, size_a, b_m, ldb, size_b, beta, c_orc,
-                             ldc, size_c, batch=batch, batch_type=0, form=form, depth=depth, k_chunk=k_chunk,
-                             a_off=offset, b_off=offset, c_off=offset)
-    assert st == 0
-    c_blas = c_m.copy()
-    for i in range(batch):
-        openblas_gemm(transa, transb, m, n, k, alpha, a_m, i * size_a + offset, lda, b_m, i * size_b + offset,
-                      ldb, beta, c_blas, i * size_c + offset, ldc)
 
     a_d, b_d, c_d = a_m, b_m, c_m
     inter = batch > 1 and batch_type == interleaved
@@ -149,6 +138,21 @@ def verify_gemm(h, dtype, offset, batch, m, n, k, transa, transb, alpha, beta, l
     c_gpu = run_device(h, call, a_d, b_d, c_d)
     if inter:
         c_gpu = from_interleaved(c_gpu, offset, ldc, n, batch)
+
+    # ground truth 1: the oracle (bitwise).  A split-K launch is reproduced with
+    # the cut the library reports; everything else is the plain k-ordered chain.
+    depth, k_chunk = h.last_splitk()
+    form = oracle.FORM_SPLITK if depth > 1 else oracle.FORM_REF
+    c_orc = c_m.copy()
+    st = oracle.gemm_backend(transa, transb, m, n, k, alpha, a_m, lda, size_a, b_m, ldb, size_b, beta, c_orc,
+                             ldc, size_c, batch=batch, batch_type=0, form=form, depth=depth, k_chunk=k_chunk,
+                             a_off=offset, b_off=offset, c_off=offset)
+    assert st == 0
+    # ground truth 2: OpenBLAS under the reference's predicate
+    c_blas = c_m.copy()
+    for i in range(batch):
+        openblas_gemm(transa, transb, m, n, k, alpha, a_m, i * size_a + offset, lda, b_m, i * size_b + offset,
+                      ldb, beta, c_blas, i * size_c + offset, ldc)
     what = f"gemm {np.dtype(dtype).name} off={offset} batch={batch} {m}x{n}x{k} {transa}{transb} a={alpha} b={beta}"
     assert_reference_predicate(c_gpu, c_blas, what)
     if exact:

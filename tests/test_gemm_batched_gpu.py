@@ -1,0 +1,79 @@
+"""GPU parity tests for blas::_gemm_batched and blas::_gemm_strided_batched: the
+reference's grids (test/unittest/blas3/blas3_gemm_batched_test.cpp:29-147)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from sycl_blas_amd import _lib
+
+from common import interleaved, strided, verify_gemm, verify_gemm_strided
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.float32, np.float64]
+
+
+def grid(*axes):
+    return list(itertools.product(*axes))
+
+
+# (offset, batch, m, n, k, transa, transb, alpha, beta, lda_mul, ldb_mul, ldc_mul, batch_type)
+BETA_NONZERO_LD_MATCH = grid([0, 33], [5], [63, 128], [63, 128], [63, 128], "nt", "nt", [3.0], [7.0], [1], [1], [1], [strided])
+BETA_NONZERO_LD_MULTIPLIED = grid([0, 33], [1, 5], [63, 128, 129], [63, 128, 129], [63, 128, 129], "nt", "nt", [3.0], [7.0],
+                                  [2], [3], [4], [strided, interleaved])
+BETA_NONZERO_LD_MATCH_ALPHA0 = grid([0], [5], [128], [128], [128], "nt", "nt", [0.0], [7.0], [1], [1], [1], [strided])
+BETA_NONZERO_LD_MULTIPLIED_ALPHA0 = grid([0, 33], [5], [63], [63], [63], "nt", "nt", [0.0], [7.0], [2], [3], [4], [strided])
+
+GRIDS = {
+    "BetaNonZeroLDMatch": BETA_NONZERO_LD_MATCH,
+    "BetaNonZeroLDMultiplied": BETA_NONZERO_LD_MULTIPLIED,
+    "BetaNonZeroLDMatchAlpha0": BETA_NONZERO_LD_MATCH_ALPHA0,
+    "BetaNonZeroLDMultipliedAlpha0": BETA_NONZERO_LD_MULTIPLIED_ALPHA0,
+}
+
+# (offset, batch, m, n, k, transa, transb, alpha, beta, lda_mul, ldb_mul, ldc_mul, sa_mul, sb_mul, sc_mul)
+DEFAULT_GEMM_AND_GEMM_BATCHED = grid([0, 33], [1, 5], [63, 128], [63, 128], [63, 128], "nt", "nt", [3.0], [7.0], [1], [1], [1],
+                                     [1], [1], [1])
+ALL_STRIDED_BATCHED = grid([0, 33], [5], [63], [63], [128], "nt", "nt", [3.0, 0.0], [7.0, 1.0, 0.0], [2], [3], [4],
+                           [0, 1, 2], [0, 1, 2], [1, 3])
+
+STRIDED_GRIDS = {
+    "DefaultGemmAndGemmBatched": DEFAULT_GEMM_AND_GEMM_BATCHED,
+    "AllStridedBatched": ALL_STRIDED_BATCHED,
+}
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("name", list(GRIDS))
+def test_gemm_batched_grid(sb_handle, name, dtype):
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    for case in GRIDS[name]:
+        *args, batch_type = case
+        verify_gemm(sb_handle, dtype, *args, batch_type=batch_type)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("name", list(STRIDED_GRIDS))
+def test_gemm_strided_batched_grid(sb_handle, name, dtype):
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    for case in STRIDED_GRIDS[name]:
+        verify_gemm_strided(sb_handle, dtype, *case)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("family", ["LARGE", "SMALL", "HUGE", "NAIVE"])
+def test_batched_every_kernel_family(sb_handle, family, dtype):
+    sb_handle.set_kernel(getattr(_lib, "KERNEL_" + family))
+    try:
+        for ta, tb in itertools.product("nt", "nt"):
+            verify_gemm_strided(sb_handle, dtype, 5, 3, 70, 33, 41, ta, tb, 1.5, 0.5, 2, 1, 3, 1, 0, 2)
+            verify_gemm_strided(sb_handle, dtype, 0, 4, 64, 64, 64, ta, tb, 1.0, 0.0, 1, 1, 1, 1, 1, 1)
+    finally:
+        sb_handle.set_kernel(_lib.KERNEL_AUTO)
+
+
+def test_config3_shape_sample(sb_handle):
+    # BASELINE config #3 at reduced batch: strided-batched SGEMM of 64x64x64 items.
+    verify_gemm_strided(sb_handle, np.float32, 0, 64, 64, 64, 64, "n", "n", 1.0, 0.0, 1, 1, 1, 1, 1, 1)
+    assert sb_handle.last_kernel() == _lib.KERNEL_SMALL

@@ -5,7 +5,7 @@ import itertools
 import numpy as np
 import pytest
 
-import oracle
+import oracle  # noqa: F401
 import sycl_blas_amd as sb
 from sycl_blas_amd import _lib
 

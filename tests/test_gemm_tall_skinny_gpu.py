@@ -1,0 +1,69 @@
+"""GPU parity tests for the tall-skinny (split-K) path: the reference's grids
+(test/unittest/blas3/blas3_gemm_tall_skinny_test.cpp:29-103)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from sycl_blas_amd import _lib
+
+from common import verify_gemm
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.float32, np.float64]
+
+
+def grid(*axes):
+    return list(itertools.product(*axes))
+
+
+# (offset, batch, m, n, k, transa, transb, alpha, beta, lda_mul, ldb_mul, ldc_mul)
+BETA_NONZERO_LD_MATCH = grid([0], [1], [7, 65], [9, 126], [2049], "nt", "nt", [1.5], [0.5], [1], [1], [1])
+BETA_NONZERO_LD_MULTIPLIED = grid([0], [1], [7, 65], [9, 126], [2049], "nt", "nt", [1.5], [0.5], [2], [3], [4])
+BETA_ZERO = grid([0], [1], [7], [9], [1026], "nt", "nt", [1.5], [0.0], [1], [1], [1])
+OFFSET_NONZERO = grid([10], [1], [7], [9], [1026], "nt", "nt", [1.5], [0.5], [1], [1], [1])
+
+GRIDS = {
+    "BetaNonZeroLDMatch": BETA_NONZERO_LD_MATCH,
+    "BetaNonZeroLDMultiplied": BETA_NONZERO_LD_MULTIPLIED,
+    "BetaZero": BETA_ZERO,
+    "OffsetNonZero": OFFSET_NONZERO,
+}
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("name", list(GRIDS))
+def test_tall_skinny_grid(sb_handle, name, dtype):
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    saw_split = False
+    for case in GRIDS[name]:
+        verify_gemm(sb_handle, dtype, *case)
+        saw_split |= sb_handle.last_kernel() == _lib.KERNEL_SPLITK
+    # k = 2049 must take the split path; k = 1026 <= 2048 takes one final
+    # partial kernel like the reference (portblas_handle.hpp:323-331).
+    assert saw_split == (name in ("BetaNonZeroLDMatch", "BetaNonZeroLDMultiplied"))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("depth", [2, 3, 7, 64])
+def test_forced_split_depths(sb_handle, depth, dtype):
+    # Any cube depth must reproduce the oracle's split-K form with the same cut,
+    # on both partial-kernel tiles (64x64 and 128x128) and on ragged edges.
+    sb_handle.set_kernel(_lib.KERNEL_SPLITK, depth)
+    try:
+        for (m, n, k), ta, tb in itertools.product([(7, 9, 300), (65, 126, 1000), (200, 130, 2049), (256, 256, 4096)],
+                                                  "nt", "nt"):
+            for alpha, beta, ldm in ((1.5, 0.5, 1), (2.0, 0.0, 3)):
+                verify_gemm(sb_handle, dtype, 0, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
+                assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK
+    finally:
+        sb_handle.set_kernel(_lib.KERNEL_AUTO)
+
+
+def test_config4_shape_sample(sb_handle):
+    # BASELINE config #4 at reduced K: SGEMM 256 x 256 x 65536 goes through split-K.
+    verify_gemm(sb_handle, np.float32, 0, 1, 256, 256, 65536, "n", "n", 1.5, 0.5, 1, 1, 1)
+    assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK
+    depth, k_chunk = sb_handle.last_splitk()
+    assert depth > 1 and depth * k_chunk >= 65536
