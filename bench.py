@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SGEMM / DGEMM at 8192^3 on MI355X through the C ABI.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one GEMM call (C <- alpha*A*B + beta*C, alpha = 1, beta = 0, the
+reference benchmark's convention: benchmark/config_csv/blas3/gemm/gemm_square.csv)
+on operands that are already resident in HBM.  Inputs are uniform in [-2, 5]
+(test/blas_test.hpp:137-140), generated on the device from a counter-based
+generator with fixed seeds.
+
+N = 1: the workload is BASELINE config #2, SGEMM 8192 x 8192 x 8192 NN.
+N > 1: one process per GPU (launched by torch.distributed.run).  The GPUs form a
+Pr x Pc grid of C blocks; rank (i, j) owns the C block (i, j) and holds the A
+row-panel i and the B column-panel j, so the inner loop exchanges nothing.
+  --mode weak   (default) every rank's block is a full 8192^3 product: the job is a
+                (Pr*8192) x (Pc*8192) x 8192 GEMM, per-GPU work fixed.
+  --mode strong the job is one 8192^3 GEMM cut into Pr x Pc blocks.
+  --gather      additionally assemble C on every rank with an RCCL all-gather
+                inside the timed region.
+Rank 0 prints ONE JSON line.  `value` is whole-job TFLOP/s = 2*M*N*K summed over
+ranks / max-over-ranks wall time of the K timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Dense MFMA peaks of one MI355X (TFLOP/s) and its HBM3E peak (GB/s).
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+PEAK_HBM_GBS = 8000.0
+NP_DTYPE = {"f32": np.float32, "f64": np.float64}
+GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)  # the reference warms up 10 calls (common_utils.hpp:1840-1845)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--trans", choices=["nn", "nt", "tn", "tt"], default="nn")
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--mode", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--gather", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    return ap.parse_args()
+
+
+class Operands:
+    """A, B, C of one rank's block product, resident in HBM (torch owns the memory)."""
+
+    def __init__(self, torch, sb, handle, dtype, ta, tb, m, n, k, seed):
+        from sycl_blas_amd import DeviceBuffer, helper
+
+        tdt = torch.float32 if dtype == "f32" else torch.float64
+        name = "float32" if dtype == "f32" else "float64"
+        self.m, self.n, self.k, self.ta, self.tb = m, n, k, ta, tb
+        self.lda = k if ta != "n" else m
+        self.ldb = n if tb != "n" else k
+        self.ldc = m
+        self.ta_t = torch.empty(m * k, dtype=tdt, device="cuda")
+        self.tb_t = torch.empty(k * n, dtype=tdt, device="cuda")
+        self.tc_t = torch.zeros(m * n, dtype=tdt, device="cuda")
+        self.a = DeviceBuffer.from_pointer(self.ta_t.data_ptr(), name, m * k, self.ta_t)
+        self.b = DeviceBuffer.from_pointer(self.tb_t.data_ptr(), name, k * n, self.tb_t)
+        self.c = DeviceBuffer.from_pointer(self.tc_t.data_ptr(), name, m * n, self.tc_t)
+        helper.fill_uniform(handle, self.a, m * k, seed)
+        helper.fill_uniform(handle, self.b, k * n, seed + 1)
+        handle.wait()
+
+    def run(self, sb, handle):
+        return sb._gemm(handle, self.ta, self.tb, self.m, self.n, self.k, 1.0, self.a, self.lda, self.b, self.ldb,
+                        0.0, self.c, self.ldc)
+
+
+def device_time_ms(sb, handle, fn, reps, warm=2):
+    """Average device time of `fn` from HIP events recorded on the stream the kernels run on."""
+    for _ in range(warm):
+        fn()
+    handle.wait()
+    e0 = handle.record_event()
+    for _ in range(reps):
+        fn()
+    e1 = handle.record_event()
+    e1.wait()
+    return e0.elapsed_ms(e1) / reps
+
+
+def cpu_baseline(dtype, ta, tb, size, seed):
+    """The CPU restatement (oracle) timed on the host cores on a bounded sample:
+    the first `cols` columns of C of the same product (same A, a column slab of B)."""
+    import oracle
+    from sycl_blas_amd import uniform_reference
+
+    npdt = NP_DTYPE[dtype]
+    m = k = size
+    cols = min(size, 512)
+    a = uniform_reference(m * k, seed).astype(npdt)
+    lda = k if ta != "n" else m
+    if tb == "n":  # B is k x n, a column slab is contiguous
+        b = uniform_reference(k * cols, seed + 1).astype(npdt)
+        ldb = k
+    else:          # B is stored n x k: take the first `cols` rows of every column
+        full = uniform_reference(size * k, seed + 1).astype(npdt).reshape(k, size)
+        b = np.ascontiguousarray(full[:, :cols]).ravel()
+        ldb = cols
+    c = np.zeros(m * cols, dtype=npdt)
+    oracle.gemm_backend(ta, tb, m, min(cols, 8), k, 1.0, a, lda, 0, b, ldb, 0, 0.0, c, m, 0)  # page in, spin up threads
+    t0 = time.perf_counter()
+    st = oracle.gemm_backend(ta, tb, m, cols, k, 1.0, a, lda, 0, b, ldb, 0, 0.0, c, m, 0)
+    dt = time.perf_counter() - t0
+    assert st == 0
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    return {
+        "value": round(2.0 * m * cols * k / dt / 1e12, 5),
+        "unit": "TFLOP/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"first {cols} of {size} columns of C of the same {dtype} {size}^3 {ta}{tb} product "
+                  f"({2.0 * m * cols * k / 1e9:.0f} GFLOP, {dt:.2f} s), OpenMP over columns",
+    }, c, cols
+
+
+def load_traffic(dtype, trans, size):
+    """HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/*.json), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        return table.get(f"{dtype}_{trans}_{size}")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the GEMM path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import sycl_blas_amd as sb
+    from sycl_blas_amd.distributed import block_of, grid_for
+
+    handle = sb.SB_Handle(local, torch.cuda.current_stream().cuda_stream)
+    ta, tb = args.trans[0], args.trans[1]
+    size = args.size
+    pr, pc = grid_for(world)
+    if args.mode == "weak":
+        gm, gn, gk = pr * size, pc * size, size
+    else:
+        gm, gn, gk = size, size, size
+    (r0, r1), (c0, c1) = block_of(rank, pr, pc, gm, gn)
+    bm, bn = r1 - r0, c1 - c0
+    ops = Operands(torch, sb, handle, args.dtype, ta, tb, bm, bn, gk, 12345 + 2 * rank)
+
+    gathered = None
+    if args.gather and world > 1:
+        gathered = torch.empty(world * bm * bn, dtype=ops.tc_t.dtype, device="cuda")
+
+    def step():
+        ops.run(sb, handle)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, ops.tc_t)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = handle.record_event()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ev1 = handle.record_event()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_ms(ev1) / args.steps  # device time per launch, events on the kernels' stream
+
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    flops_job = 2.0 * gm * gn * gk
+    value = flops_job * args.steps / wall / 1e12
+
+    if rank == 0:
+        achieved = 2.0 * bm * bn * gk / (kernel_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        out = {
+            "metric": "SGEMM/DGEMM TFLOP/s at 8192^3 + % of MI355X MFMA peak, 1/2/4/8 GPUs",
+            "value": round(value, 3),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": args.mode,
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic: uniform [-2, 5], counter-based generator on the device, seed 12345",
+            "config": {
+                "workload": f"{'S' if args.dtype == 'f32' else 'D'}GEMM {size}x{size}x{size} {args.trans.upper()} "
+                            f"per GPU C-block, alpha=1 beta=0, through sbamd_{'s' if args.dtype == 'f32' else 'd'}gemm",
+                "job": f"{gm}x{gn}x{gk}",
+                "grid": f"{pr}x{pc} C blocks",
+                "gather": bool(gathered is not None),
+                "pct_of_mfma_peak_per_gpu": round(100.0 * value / world / peak, 2),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": round(achieved, 3),
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4),
+                "traffic": load_traffic(args.dtype, args.trans, size),
+                "kernel": f"gemm_mfma_kernel<{'float' if args.dtype == 'f32' else 'double'}> (tile family "
+                          f"{handle.last_kernel()}), {kernel_ms:.4f} ms per launch",
+            },
+        }
+
+        if not args.no_extras and world == 1:
+            extras = {}
+            for dt, tr in (("f32", "nt"), ("f64", "nn"), ("f64", "nt")):
+                o = Operands(torch, sb, handle, dt, tr[0], tr[1], size, size, size, 777)
+                ms = device_time_ms(sb, handle, lambda: o.run(sb, handle), 5)
+                tf = 2.0 * size ** 3 / ms / 1e9
+                extras[f"{dt}_{tr}_{size}"] = {"ms": round(ms, 4), "tflops": round(tf, 2),
+                                               "pct_peak": round(100 * tf / PEAK_TFLOPS[dt], 2)}
+                del o
+            out["extras"] = extras
+
+        if not args.no_cpu and world == 1:
+            try:
+                base, c_cpu, cols = cpu_baseline(args.dtype, ta, tb, size, 12345)
+                out["cpu_baseline"] = base
+                # the GPU result of the same product must equal the CPU restatement bit for bit
+                got = np.empty(size * cols, dtype=NP_DTYPE[args.dtype])
+                handle.wait(sb.helper.copy_to_host(handle, ops.c, got, got.size))
+                out["config"]["cpu_sample_bitwise_equal"] = bool(np.array_equal(got.view(np.uint8), c_cpu.view(np.uint8)))
+            except Exception as exc:  # the baseline is a reported extra, never the product path
+                out["cpu_baseline"] = {"value": None, "unit": "TFLOP/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {exc!r}"}
+        print(json.dumps(out), flush=True)
+
+    handle.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,8 +144,10 @@ def verify_gemm(h, dtype, offset, batch, m, n, k, transa, transb, alpha, beta, l
     depth, k_chunk = h.last_splitk()
     form = oracle.FORM_SPLITK if depth > 1 else oracle.FORM_REF
     c_orc = c_m.copy()
-    st = oracle.gemm_backend(transa, transb, m, n, k, alpha, a_m, lda, size_a, b_m, ldb, size_b, beta, c_orc,
-                             ldc, size_c, batch=batch, batch_type=0, form=form, depth=depth, k_chunk=k_chunk,
+    # blas::_gemm passes zero strides (gemm_interface.hpp:194-197); _gemm_batched whole matrices (:213-219)
+    o_sa, o_sb, o_sc = (0, 0, 0) if batch == 1 else (size_a, size_b, size_c)
+    st = oracle.gemm_backend(transa, transb, m, n, k, alpha, a_m, lda, o_sa, b_m, ldb, o_sb, beta, c_orc,
+                             ldc, o_sc, batch=batch, batch_type=0, form=form, depth=depth, k_chunk=k_chunk,
                              a_off=offset, b_off=offset, c_off=offset)
     assert st == 0
     # ground truth 2: OpenBLAS under the reference's predicate

@@ -1,0 +1,123 @@
+"""world_size-2 (and 4) CPU tests of the multi-GPU layer over gloo: the C-block
+partition, the all-gather of C and the split-K reduce-scatter.  The local GEMM on
+these CPU ranks is the oracle (test stand-in for the HIP library)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from sycl_blas_amd import distributed as D  # noqa: E402
+
+
+class HostView:
+    """numpy-backed stand-in for DeviceBuffer: `+ n` advances by n elements."""
+
+    def __init__(self, arr, off=0):
+        self.arr, self.off = arr, off
+
+    def __add__(self, n):
+        return HostView(self.arr, self.off + int(n))
+
+
+def oracle_gemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
+    import oracle
+
+    st = oracle.gemm_backend(ta, tb, m, n, k, alpha, a.arr, lda, 0, b.arr, ldb, 0, beta, c.arr, ldc, 0,
+                             a_off=a.off, b_off=b.off, c_off=c.off)
+    assert st == 0
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, case, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ta, tb, m, n, k = case
+        rng = np.random.default_rng(99)  # same inputs on every rank (replicated operands)
+        lda = (k if ta != "n" else m) + 3
+        ldb = (n if tb != "n" else k) + 2
+        a = rng.uniform(-2, 5, lda * (m if ta != "n" else k)).astype(np.float32)
+        b = rng.uniform(-2, 5, ldb * (k if tb != "n" else n)).astype(np.float32)
+        c0 = rng.uniform(-2, 5, m * n).astype(np.float32)
+        want = c0.copy()
+        oracle_gemm(ta, tb, m, n, k, 1.5, HostView(a), lda, HostView(b), ldb, 0.5, HostView(want), m)
+
+        # 2-D C blocks, written in place into a full-size C, then gathered
+        pr, pc = D.grid_for(world)
+        c_full = c0.copy()
+        (r0, r1), (q0, q1) = D.block_gemm(oracle_gemm, rank, pr, pc, ta, tb, m, n, k, 1.5, HostView(a), lda,
+                                          HostView(b), ldb, 0.5, HostView(c_full), m)
+        mine = np.ascontiguousarray(c_full.reshape(n, m)[q0:q1, r0:r1]).ravel()
+        outside = np.ones((n, m), bool)
+        outside[q0:q1, r0:r1] = False
+        assert np.array_equal(c_full.reshape(n, m)[outside], c0.reshape(n, m)[outside])  # only the own block is written
+        gathered = D.all_gather_c(dist, torch, torch.from_numpy(mine), rank, pr, pc, m, n).numpy()
+        ok_blocks = np.array_equal(gathered, want)
+
+        # panels-only form: the rank holds just its row-panel / column-panel / block
+        a_off, b_off = D.panel_offsets(rank, pr, pc, ta, tb, m, n, lda, ldb)
+        blk = np.ascontiguousarray(c0.reshape(n, m)[q0:q1, r0:r1]).ravel()
+        D.block_gemm(oracle_gemm, rank, pr, pc, ta, tb, m, n, k, 1.5, HostView(a, a_off), lda, HostView(b, b_off), ldb,
+                     0.5, HostView(blk), max(r1 - r0, 1), full_operands=False)
+        ok_panels = np.array_equal(blk, mine)
+
+        # split-K across ranks + reduce-scatter (sum order differs -> tolerance)
+        ok_splitk = True
+        if n % world == 0:
+            def make_buffer(count):
+                t = torch.zeros(count, dtype=torch.float32)
+                return t, HostView(t.numpy())
+            slab, (s0, s1) = D.splitk_gemm(dist, torch, oracle_gemm, make_buffer, rank, world, ta, tb, m, n, k, 1.5,
+                                           HostView(a), lda, HostView(b), ldb)
+            ref = c0.copy() * 0
+            oracle_gemm(ta, tb, m, n, k, 1.5, HostView(a), lda, HostView(b), ldb, 0.0, HostView(ref), m)
+            ok_splitk = np.allclose(slab.numpy(), ref.reshape(n, m)[s0:s1].ravel(), rtol=2e-5, atol=1e-3)
+        ret[rank] = (ok_blocks, ok_panels, ok_splitk)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case", [("n", "n", 37, 24, 19), ("t", "n", 16, 8, 33), ("n", "t", 5, 12, 7), ("t", "t", 64, 64, 8)])
+def test_block_partition_and_collectives(world, case):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, case, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r] == (True, True, True), (r, ret[r])
+
+
+def test_partition_covers_c_exactly_once():
+    for world in (1, 2, 3, 4, 6, 8):
+        pr, pc = D.grid_for(world)
+        assert pr * pc == world and pr <= pc
+        for m, n in ((8192, 8192), (7, 9), (65536, 65536), (5, 3)):
+            seen = np.zeros((min(m, 64), min(n, 64)), np.int32)
+            total = 0
+            for r in range(world):
+                (a0, a1), (b0, b1) = D.block_of(r, pr, pc, m, n)
+                total += (a1 - a0) * (b1 - b0)
+                seen[min(a0, 64):min(a1, 64), min(b0, 64):min(b1, 64)] += 1
+            assert total == m * n
+            assert (seen == 1).all()
+    assert D.grid_for(8) == (2, 4) and D.grid_for(4) == (2, 2) and D.grid_for(2) == (1, 2)
