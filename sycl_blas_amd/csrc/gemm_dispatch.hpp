@@ -24,10 +24,10 @@ inline bool vec_ok(const T* p, int64_t ld, int64_t stride, int64_t batch) {
          (batch <= 1 || stride % V == 0);
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB>
 hipError_t launch_one(const GemmArgs<T>& g, int64_t nz, hipStream_t stream) {
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
-  auto kernel = gemm_mfma_kernel<T, BM, BN, BK, WM, WN, TA, TB>;
+  auto kernel = gemm_mfma_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -42,17 +42,17 @@ hipError_t launch_one(const GemmArgs<T>& g, int64_t nz, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC = 1>
 hipError_t launch_tile(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
   g.tiles_m = int32_t(ceil_div(g.m, BM));
   g.tiles_n = int32_t(ceil_div(g.n, BN));
   const int64_t nz = g.split_k > 1 ? g.split_k : g.batch;
   if (ta) {
-    return tb ? launch_one<T, BM, BN, BK, WM, WN, true, true>(g, nz, stream)
-              : launch_one<T, BM, BN, BK, WM, WN, true, false>(g, nz, stream);
+    return tb ? launch_one<T, BM, BN, BK, WM, WN, OCC, true, true>(g, nz, stream)
+              : launch_one<T, BM, BN, BK, WM, WN, OCC, true, false>(g, nz, stream);
   }
-  return tb ? launch_one<T, BM, BN, BK, WM, WN, false, true>(g, nz, stream)
-            : launch_one<T, BM, BN, BK, WM, WN, false, false>(g, nz, stream);
+  return tb ? launch_one<T, BM, BN, BK, WM, WN, OCC, false, true>(g, nz, stream)
+            : launch_one<T, BM, BN, BK, WM, WN, OCC, false, false>(g, nz, stream);
 }
 
 template <typename T>
@@ -86,18 +86,20 @@ hipError_t launch_naive(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stre
   return hipGetLastError();
 }
 
-// Tile families.  BK is 16 for fp32 and 8 for fp64 in the small family so a
-// 64 x 64 x 64 batched item is staged in four steps; the large families take a
-// deeper K step so K-major operands are fetched in whole 128-byte lines.
+// Tile families and their K steps, picked by measurement at 8192^3 on MI355X
+// (TFLOP/s NN / NT / TN):
+//   fp32 256x128x32: 136.6 / 134.3 / 137.1    128x128x16: 132.9 / 134.9 / 135.0
+//   fp64 256x128x16:  73.4 /  73.4 /  73.6    128x128x8 :  71.6 /  71.9 /  71.9
+// The small family stages a 64 x 64 x 64 batched item in four steps.
 template <typename T>
 struct Tiles;
 template <>
 struct Tiles<float> {
-  static constexpr int LARGE_BK = 32, SMALL_BK = 16, HUGE_BK = 16;
+  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 32;
 };
 template <>
 struct Tiles<double> {
-  static constexpr int LARGE_BK = 16, SMALL_BK = 8, HUGE_BK = 8;
+  static constexpr int LARGE_BK = 8, SMALL_BK = 8, HUGE_BK = 16;
 };
 
 // The reference's tall-skinny predicate (amd_gpu.hpp:77-81).
@@ -144,9 +146,22 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     if (is_tall_skinny(p.m, p.n, p.k, p.batch)) {
       family = SBAMD_KERNEL_SPLITK;
     } else {
-      // Large tiles only when they still give every compute unit work.
-      const int64_t large_tiles = ceil_div(p.m, 128) * ceil_div(p.n, 128) * p.batch;
-      family = large_tiles >= cus ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
+      // The biggest tile that (a) is mostly filled by the matrix and (b) still
+      // gives every compute unit a workgroup; otherwise the 64x64 tile, whose
+      // many small workgroups keep the chip occupied on small and batched shapes
+      // (the role of the reference's low-arithmetic-ratio configurations,
+      // amd_gpu.hpp:242-271).
+      auto fits = [&](int bm, int bn) {
+        const int64_t tm = ceil_div(p.m, bm), tn = ceil_div(p.n, bn);
+        const double fill = double(p.m) * double(p.n) / (double(tm * bm) * double(tn * bn));
+        return fill >= 0.75 && tm * tn * p.batch >= cus;
+      };
+      // (fp32 with both operands transposed measured 112 TFLOP/s on the 256x128
+      // tile against 136 on the 128x128 one at 8192^3, so it skips the big tile.)
+      const bool skip_huge = sizeof(T) == 4 && p.ta && p.tb;
+      if (!skip_huge && fits(256, 128)) family = SBAMD_KERNEL_HUGE;
+      else if (fits(128, 128)) family = SBAMD_KERNEL_LARGE;
+      else family = SBAMD_KERNEL_SMALL;
     }
   }
 
@@ -177,7 +192,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       gp.k_chunk = k_chunk;
       gp.slice_stride = slice;
       gp.beta_zero = 1;
-      e = big ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2>(gp, p.ta, p.tb, h->stream)
+      e = big ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream)
               : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
       if (e != hipSuccess) return e;
       const int64_t grid = ceil_div(slice, 256);
@@ -195,7 +210,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   h->last_kernel = family;
   switch (family) {
     case SBAMD_KERNEL_LARGE:
-      return launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2>(g, p.ta, p.tb, h->stream);
+      return launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(g, p.ta, p.tb, h->stream);
     case SBAMD_KERNEL_HUGE:
       return launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(g, p.ta, p.tb, h->stream);
     case SBAMD_KERNEL_SMALL:

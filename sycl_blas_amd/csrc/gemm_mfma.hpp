@@ -127,6 +127,7 @@ struct TileLoader {
   static_assert(BK % 4 == 0, "K step is handled in groups of four");
   static constexpr int NV = NVEC / NT;
   static constexpr int PER_ROW = KMAJOR ? (BK / V) : (BMN / V);
+  static constexpr int NWRITE = NV * ((KMAJOR && V == 4) ? 2 : 1);  // LDS store instructions per tile
 
   T reg[NV][V];
 
@@ -321,43 +322,144 @@ struct GemmBody {
     }
   }
 
-  // FAST: this workgroup's tile is interior and both operands allow 16-byte
-  // loads; whole K steps then use load_fast, only a K tail uses load_edge.
-  template <bool FAST>
-  __device__ inline void run(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
-                             int64_t k_begin, int64_t k_end, SBAMD_LDS T* smem, int tid, int a_mn,
-                             int b_mn) {
+  // ---- pipelined path (interior tiles, aligned operands) -------------------
+  //
+  // Iteration kt computes tile kt out of LDS buffer kt & 1 while
+  //   * the registers loaded one whole iteration ago (tile kt + 1) are stored
+  //     to the other buffer at the top of the iteration, and
+  //   * the global loads of tile kt + 2 are issued right behind that store,
+  // so every global load has a full K step of matrix work to land.  The one
+  // barrier per step sits in front of the LAST fragment group's MFMAs: by then
+  // every fragment of tile kt is in registers (the buffer may be overwritten
+  // next iteration) and every wave's store of tile kt + 1 has completed, so the
+  // first fragments of tile kt + 1 are fetched behind the barrier and their
+  // latency hides under the last group's matrix instructions.
+  using frag_a_t = T[2][K::MI][M::GS];
+  using frag_b_t = T[2][K::NI][M::GS];
+
+  __device__ inline void fetch_group(const SBAMD_LDS T* as, const SBAMD_LDS T* bs, int grp, int a_mn,
+                                     int b_mn, int lane, T (&fa)[K::MI][M::GS], T (&fb)[K::NI][M::GS]) {
+#pragma unroll
+    for (int i = 0; i < K::MI; ++i) LoadA::fragment(as, grp, a_mn + i * M::T, lane, fa[i]);
+#pragma unroll
+    for (int j = 0; j < K::NI; ++j) LoadB::fragment(bs, grp, b_mn + j * M::T, lane, fb[j]);
+  }
+
+  __device__ inline void mma_group(const T (&fa)[K::MI][M::GS], const T (&fb)[K::NI][M::GS]) {
+#pragma unroll
+    for (int e = 0; e < M::GS; ++e)
+#pragma unroll
+      for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < K::NI; ++j) acc[i][j] = M::mma(fb[j][e], fa[i][e], acc[i][j]);
+  }
+
+  // One K step of the pipelined path.  Group 0 of this tile is already in
+  // fa[0] / fb[0]; on return group 0 of the next tile is (HAS_NEXT).
+  // NWRITE / NVMEM: LDS stores and global loads issued by the caller at the top
+  // of the step, placed behind the first MFMAs by the scheduling pattern.
+  template <bool HAS_NEXT, int NWRITE, int NVMEM>
+  __device__ inline void pipelined_step(const SBAMD_LDS T* as, const SBAMD_LDS T* bs,
+                                        const SBAMD_LDS T* nas, const SBAMD_LDS T* nbs, int a_mn,
+                                        int b_mn, int lane, frag_a_t& fa, frag_b_t& fb) {
+    static_assert(K::NGRP % 2 == 0, "fragment double buffer must come back to slot 0");
+    constexpr int NM = K::MI * K::NI * M::GS;
+#pragma unroll
+    for (int grp = 0; grp + 1 < K::NGRP; ++grp) {
+      fetch_group(as, bs, grp + 1, a_mn, b_mn, lane, fa[(grp + 1) & 1], fb[(grp + 1) & 1]);
+      mma_group(fa[grp & 1], fb[grp & 1]);
+    }
+    // 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write
+    constexpr int SLOTS = K::MI + K::NI;
+    constexpr int STRIDE = NM / SLOTS > 0 ? NM / SLOTS : 1;
+    constexpr int PER = SLOTS / NM > 0 ? SLOTS / NM : 1;
+#pragma unroll
+    for (int n = 0; n < (K::NGRP - 1) * NM; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (n < NWRITE) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      else if (n < NWRITE + NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (n % STRIDE == 0) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+    }
+    __syncthreads();
+    if (HAS_NEXT) fetch_group(nas, nbs, 0, a_mn, b_mn, lane, fa[0], fb[0]);
+    mma_group(fa[(K::NGRP - 1) & 1], fb[(K::NGRP - 1) & 1]);
+  }
+
+  __device__ inline void run_pipelined(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0,
+                                       int64_t n0, int64_t k_begin, int64_t k_end, SBAMD_LDS T* smem,
+                                       int tid, int a_mn, int b_mn) {
+    const int lane = tid & 63;
+    const int64_t klen = k_end - k_begin;
+    const int nfull = int(klen / BK);  // >= 1 (checked by the caller)
+    constexpr int NW = LoadA::NWRITE + LoadB::NWRITE;
+    constexpr int NL = LoadA::NV + LoadB::NV;
+    SBAMD_LDS T* const buf0 = smem;
+    SBAMD_LDS T* const buf1 = smem + K::STAGE_ELEMS;
+
+    la.load_fast(a, g.lda, m0, k_begin, tid);
+    lb.load_fast(b, g.ldb, n0, k_begin, tid);
+    la.store(buf0, tid);
+    lb.store(buf0 + K::A_ELEMS, tid);
+    if (nfull > 1) {
+      la.load_fast(a, g.lda, m0, k_begin + BK, tid);
+      lb.load_fast(b, g.ldb, n0, k_begin + BK, tid);
+    }
+    __syncthreads();
+    frag_a_t fa;
+    frag_b_t fb;
+    fetch_group(buf0, buf0 + K::A_ELEMS, 0, a_mn, b_mn, lane, fa[0], fb[0]);
+
+    int kt = 0;
+    for (; kt + 2 < nfull; ++kt) {
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
+      la.store(nxt, tid);
+      lb.store(nxt + K::A_ELEMS, tid);
+      const int64_t k2 = k_begin + int64_t(kt + 2) * BK;
+      la.load_fast(a, g.lda, m0, k2, tid);
+      lb.load_fast(b, g.ldb, n0, k2, tid);
+      pipelined_step<true, NW, NL>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
+    }
+    if (kt + 1 < nfull) {  // last but one: nothing left to load
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
+      la.store(nxt, tid);
+      lb.store(nxt + K::A_ELEMS, tid);
+      pipelined_step<true, NW, 0>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
+      ++kt;
+    }
+    {
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      pipelined_step<false, 0, 0>(cur, cur + K::A_ELEMS, cur, cur + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
+    }
+    // K tail (< BK): one unpipelined step.  The barrier inside the last step
+    // came after every fragment read, so both buffers are free.
+    const int64_t k_tail = k_begin + int64_t(nfull) * BK;
+    if (k_tail < k_end) {
+      la.load_edge(a, g.lda, m0, g.m, k_tail, k_end, tid);
+      lb.load_edge(b, g.ldb, n0, g.n, k_tail, k_end, tid);
+      la.store(buf0, tid);
+      lb.store(buf0 + K::A_ELEMS, tid);
+      __syncthreads();
+      compute<0>(buf0, buf0 + K::A_ELEMS, a_mn, b_mn, lane);
+    }
+  }
+
+  // ---- simple path (edge tiles, unaligned operands): element loads, one
+  // barrier per K step, loads of the next tile issued before the compute.
+  __device__ inline void run_edge(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
+                                  int64_t k_begin, int64_t k_end, SBAMD_LDS T* smem, int tid, int a_mn,
+                                  int b_mn) {
     const int lane = tid & 63;
     const int64_t klen = k_end > k_begin ? k_end - k_begin : 0;
-    const int nfull = FAST ? int(klen / BK) : 0;
     const int nk = int((klen + BK - 1) / BK);
     if (nk == 0) return;
-
-    if (FAST && nfull > 0) {
-      la.load_fast(a, g.lda, m0, k_begin, tid);
-      lb.load_fast(b, g.ldb, n0, k_begin, tid);
-    } else {
-      la.load_edge(a, g.lda, m0, g.m, k_begin, k_end, tid);
-      lb.load_edge(b, g.ldb, n0, g.n, k_begin, k_end, tid);
-    }
+    la.load_edge(a, g.lda, m0, g.m, k_begin, k_end, tid);
+    lb.load_edge(b, g.ldb, n0, g.n, k_begin, k_end, tid);
     la.store(smem, tid);
     lb.store(smem + K::A_ELEMS, tid);
     __syncthreads();
-
     int kt = 0;
-    if (FAST) {
-      // steady state: the next tile is a whole K step
-      for (; kt + 1 < nfull; ++kt) {
-        const int64_t k0 = k_begin + int64_t(kt + 1) * BK;
-        la.load_fast(a, g.lda, m0, k0, tid);
-        lb.load_fast(b, g.ldb, n0, k0, tid);
-        compute<LoadA::NV + LoadB::NV>(smem + (kt & 1) * K::STAGE_ELEMS, smem + (kt & 1) * K::STAGE_ELEMS + K::A_ELEMS, a_mn, b_mn, lane);
-        la.store(smem + ((kt + 1) & 1) * K::STAGE_ELEMS, tid);
-        lb.store(smem + ((kt + 1) & 1) * K::STAGE_ELEMS + K::A_ELEMS, tid);
-        __syncthreads();
-      }
-    }
-    // remaining tiles (all of them when !FAST; at most the K tail when FAST)
     for (; kt + 1 < nk; ++kt) {
       const int64_t k0 = k_begin + int64_t(kt + 1) * BK;
       la.load_edge(a, g.lda, m0, g.m, k0, k_end, tid);
@@ -371,8 +473,9 @@ struct GemmBody {
   }
 };
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
-__global__ void __launch_bounds__(WM* WN * 64)
+// OCC = waves per SIMD the register allocation must leave room for.
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC>
+__global__ void __launch_bounds__(WM* WN * 64, OCC)
     gemm_mfma_kernel(const GemmArgs<T> g) {
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
   using M = Mfma<T>;
@@ -420,10 +523,10 @@ __global__ void __launch_bounds__(WM* WN * 64)
   const int a_mn = wm * K::WTM + frag_mn;
   const int b_mn = wn * K::WTN + frag_mn;
   const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
-  if (interior && g.vec_a && g.vec_b) {
-    body.template run<true>(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
+  if (interior && g.vec_a && g.vec_b && k_end - k_begin >= BK) {
+    body.run_pipelined(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
   } else {
-    body.template run<false>(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
+    body.run_edge(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
   }
 
   // ---- epilogue: C = alpha * acc (+ beta * C); products and the sum round

@@ -14,13 +14,14 @@ rows = {}
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
-        cur = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
         cur = re.sub(r"sbamd::|void |\(sbamd::GemmArgs<\w+>\)", "", cur)
         rows[cur] = {}
         continue
-    m = re.search(r"remark:\s+(VGPRs|AGPRs|Occupancy \[waves/SIMD\]|VGPRs Spill|TotalSGPRs|LDS Size \[bytes/block\]): (\d+)", line)
+    m = re.search(r"remark:\s+(VGPRs Spill|VGPRs|AGPRs|Occupancy \[waves/SIMD\]|TotalSGPRs): (\d+)", line)
     if m and cur:
-        rows[cur][m.group(1).split()[0]] = int(m.group(2))
+        rows[cur][m.group(1)] = int(m.group(2))
 for name, r in rows.items():
     if flt in name:
-        print(f"{name:70s} vgpr={r.get('VGPRs')} agpr={r.get('AGPRs')} sgpr={r.get('TotalSGPRs')} occ={r.get('Occupancy')} spill={r.get('VGPRs', 0) and r.get('VGPRs Spill', r.get('VGPRs'))}")
+        print(f"{name:70s} vgpr={r.get('VGPRs')} agpr={r.get('AGPRs')} sgpr={r.get('TotalSGPRs')} "
+              f"occ={r.get('Occupancy [waves/SIMD]')} spill={r.get('VGPRs Spill')}")

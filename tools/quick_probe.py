@@ -64,6 +64,31 @@ def bench(h, dtype, m, n, k, ta, tb, fam, reps=5, param=0):
         helper.deallocate(buf)
 
 
+def bench_batched(h, dtype, m, n, k, batch, reps=20):
+    sa, sb_, sc = m * k, k * n, m * n
+    a_g = helper.allocate(h, dtype, sa * batch)
+    b_g = helper.allocate(h, dtype, sb_ * batch)
+    c_g = helper.allocate(h, dtype, sc * batch)
+    helper.fill_uniform(h, a_g, sa * batch, 1)
+    helper.fill_uniform(h, b_g, sb_ * batch, 2)
+    h.set_kernel(_lib.KERNEL_AUTO)
+    run = lambda: sb._gemm_strided_batched(h, "n", "n", m, n, k, 1.0, a_g, m, sa, b_g, k, sb_, 0.0, c_g, m, sc, batch)
+    for _ in range(3):
+        run()
+    h.wait()
+    e0 = h.record_event()
+    for _ in range(reps):
+        run()
+    e1 = h.record_event()
+    e1.wait()
+    ms = e0.elapsed_ms(e1) / reps
+    nbytes = (sa + sb_ + sc) * batch * np.dtype(dtype).itemsize
+    print(f"BENCH batched {np.dtype(dtype).name} {batch}x{m}x{n}x{k}: {ms * 1e3:.1f} us  "
+          f"{2.0 * m * n * k * batch / ms / 1e9:.1f} TFLOP/s  {nbytes / ms / 1e6:.0f} GB/s  kernel={h.last_kernel()}", flush=True)
+    for buf in (a_g, b_g, c_g):
+        helper.deallocate(buf)
+
+
 def main():
     h = sb.SB_Handle(0)
     print("CUs", h.get_num_compute_units(), flush=True)
@@ -75,15 +100,19 @@ def main():
                     ok &= run_case(h, dtype, 96, 80, 40, ta, tb, 1.5, 0.5, fam)
             ok &= run_case(h, dtype, 129, 67, 37, "n", "n", 1.5, 0.0, fam)
             ok &= run_case(h, dtype, 256, 256, 256, "n", "t", 1.0, 0.0, fam)
-        ok &= run_case(h, dtype, 200, 130, 2049, "n", "n", 1.5, 0.5, _lib.KERNEL_SPLITK, 5)
     print("ALL EXACT" if ok else "SOME MISMATCH", flush=True)
     if "--bench" in sys.argv:
         for dtype in (np.float32, np.float64):
             for fam in (_lib.KERNEL_LARGE, _lib.KERNEL_HUGE):
-                for ta, tb in (("n", "n"), ("n", "t"), ("t", "n")):
-                    bench(h, dtype, 4096, 4096, 4096, ta, tb, fam)
-            bench(h, dtype, 8192, 8192, 8192, "n", "n", _lib.KERNEL_LARGE, reps=3)
-            bench(h, dtype, 8192, 8192, 8192, "n", "n", _lib.KERNEL_HUGE, reps=3)
+                for ta, tb in (("n", "n"), ("n", "t"), ("t", "n"), ("t", "t")):
+                    bench(h, dtype, 8192, 8192, 8192, ta, tb, fam, reps=3)
+            for n in (1024, 2048, 4096):
+                bench(h, dtype, n, n, n, "n", "n", _lib.KERNEL_AUTO, reps=10)
+        bench_batched(h, np.float32, 64, 64, 64, 4096)
+        bench_batched(h, np.float64, 64, 64, 64, 4096)
+        for kk in (65536, 1 << 20, 1 << 22):
+            bench(h, np.float32, 256, 256, kk, "n", "n", _lib.KERNEL_AUTO, reps=3)
+            print("   splitk cut", h.last_splitk(), flush=True)
     h.close()
 
 
