@@ -1,0 +1,101 @@
+// 16-bit storage back end: half -> half, half -> float, bfloat16 -> float.
+#include "gemm_dispatch.hpp"
+#include "gemm_half.hpp"
+
+namespace sbamd {
+namespace {
+
+template <typename Tag, typename TOut, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+hipError_t launch16_one(const GemmArgs16<TOut>& g, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr size_t lds = 2 * size_t(TileLoader16<BM, BK, NT, TA>::ELEMS + TileLoader16<BN, BK, NT, !TB>::ELEMS) * 2;
+  auto kernel = gemm_mfma16_kernel<Tag, TOut, BM, BN, BK, WM, WN, TA, TB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * g.batch;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds, stream, g);
+  return hipGetLastError();
+}
+
+template <typename Tag, typename TOut, int BM, int BN, int BK, int WM, int WN>
+hipError_t launch16(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream) {
+  g.tiles_m = int32_t(ceil_div(g.m, BM));
+  g.tiles_n = int32_t(ceil_div(g.n, BN));
+  if (ta) {
+    return tb ? launch16_one<Tag, TOut, BM, BN, BK, WM, WN, true, true>(g, stream)
+              : launch16_one<Tag, TOut, BM, BN, BK, WM, WN, true, false>(g, stream);
+  }
+  return tb ? launch16_one<Tag, TOut, BM, BN, BK, WM, WN, false, true>(g, stream)
+            : launch16_one<Tag, TOut, BM, BN, BK, WM, WN, false, false>(g, stream);
+}
+
+inline bool vec16_ok(const uint16_t* p, int64_t ld, int64_t stride, int64_t batch) {
+  return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 8 == 0) && (batch <= 1 || stride % 8 == 0);
+}
+
+template <typename Tag, typename TOut>
+hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float beta) {
+  if (p.interleaved) return hipErrorNotSupported;
+  GemmArgs16<TOut> g;
+  g.a = p.a;
+  g.b = p.b;
+  g.c = p.c;
+  g.m = p.m;
+  g.n = p.n;
+  g.k = p.k;
+  g.lda = p.lda;
+  g.ldb = p.ldb;
+  g.ldc = p.ldc;
+  g.stride_a = p.stride_a;
+  g.stride_b = p.stride_b;
+  g.stride_c = p.stride_c;
+  g.batch = int32_t(p.batch);
+  g.tiles_m = g.tiles_n = 0;
+  g.vec_a = vec16_ok(p.a, p.lda, p.stride_a, p.batch) ? 1 : 0;
+  g.vec_b = vec16_ok(p.b, p.ldb, p.stride_b, p.batch) ? 1 : 0;
+  g.alpha = alpha;
+  g.beta = beta;
+  g.beta_zero = p.beta_zero ? 1 : 0;
+
+  const int cus = h->compute_units > 0 ? h->compute_units : 256;
+  int family = h->kernel_override;
+  if (family != SBAMD_KERNEL_LARGE && family != SBAMD_KERNEL_SMALL) {
+    const int64_t tm = ceil_div(p.m, 128), tn = ceil_div(p.n, 128);
+    const double fill = double(p.m) * double(p.n) / (double(tm * 128) * double(tn * 128));
+    family = (fill >= 0.75 && tm * tn * p.batch >= cus) ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
+  }
+  h->last_kernel = family;
+  if (family == SBAMD_KERNEL_LARGE) return launch16<Tag, TOut, 128, 128, 64, 2, 2>(g, p.ta, p.tb, h->stream);
+  return launch16<Tag, TOut, 64, 64, 32, 2, 2>(g, p.ta, p.tb, h->stream);
+}
+
+}  // namespace
+
+hipError_t run_gemm_h(Handle* h, const Problem<uint16_t, uint16_t>& p, float alpha, float beta) {
+  return run16<HalfTag, uint16_t>(h, p, alpha, beta);
+}
+hipError_t run_gemm_hs(Handle* h, const Problem<uint16_t, float>& p, float alpha, float beta) {
+  return run16<HalfTag, float>(h, p, alpha, beta);
+}
+hipError_t run_gemm_bs(Handle* h, const Problem<uint16_t, float>& p, float alpha, float beta) {
+  return run16<Bf16Tag, float>(h, p, alpha, beta);
+}
+
+hipError_t run_scale_f16(Handle* h, uint16_t* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride,
+                         int64_t batch, float beta, bool assign_zero) {
+  const int64_t total = rows * cols * batch;
+  if (total <= 0) return hipSuccess;
+  const int64_t grid = ceil_div(total, 256);
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(scale_matrix16_kernel, dim3((unsigned)grid), dim3(256), 0, h->stream, c, rows, cols, ld, stride,
+                     batch, beta, assign_zero ? 1 : 0);
+  return hipGetLastError();
+}
+
+}  // namespace sbamd

@@ -1,0 +1,264 @@
+// LDS-tiled MFMA GEMM for 16-bit storage (IEEE half and bfloat16 inputs,
+// fp32 accumulation) on gfx950.
+//
+// The reference instantiates half -> half and half -> float
+// (cmake/CmakeFunctionHelper.cmake:148-159) and multiplies mixed types by
+// casting both operands to float first (src/operations/blas3/gemm_common.hpp:53-59);
+// its only bfloat16 path rounds float data to bf16 while staging and accumulates
+// in float (src/operations/blas3/gemm_load_store_joint_matrix.hpp:76-81).  Here
+// every 16-bit variant feeds v_mfma_f32_32x32x16_{f16,bf16}: products of two
+// 16-bit values are exact in fp32 and the sum is kept in fp32, so the result is
+// at least as accurate as the reference's; the output is rounded once at the end.
+//
+// Both operand tiles sit in LDS as [mn][BK + 8] images, k fastest: a lane's MFMA
+// fragment (8 consecutive k of one row) is then one 16-byte read, and the
+// 16-byte row padding makes the stride an odd number of 16-byte slots so the
+// 16 lanes of a ds_read_b128 group hit 16 different slots.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_mfma.hpp"
+
+namespace sbamd {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+
+struct HalfTag {};  // IEEE binary16 storage
+struct Bf16Tag {};  // bfloat16 storage
+
+template <typename Tag>
+struct Mfma16;
+template <>
+struct Mfma16<HalfTag> {
+  __device__ static inline f32x16 mma(u16x8 op0, u16x8 op1, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, op0), __builtin_bit_cast(f16x8, op1), c,
+                                                  0, 0, 0);
+  }
+};
+template <>
+struct Mfma16<Bf16Tag> {
+  __device__ static inline f32x16 mma(u16x8 op0, u16x8 op1, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, op0), __builtin_bit_cast(bf16x8, op1),
+                                                   c, 0, 0, 0);
+  }
+};
+
+// Output conversion (one rounding, round-to-nearest-even; NaN stays NaN).
+__device__ inline float load_out(const float* p) { return *p; }
+__device__ inline float load_out(const uint16_t* p) { return float(__builtin_bit_cast(_Float16, *p)); }
+__device__ inline void store_out(float* p, float v) { *p = v; }
+__device__ inline void store_out(uint16_t* p, float v) { *p = __builtin_bit_cast(uint16_t, _Float16(v)); }
+
+template <typename TOut>
+struct GemmArgs16 {
+  const uint16_t* a;
+  const uint16_t* b;
+  TOut* c;
+  int64_t m, n, k;
+  int64_t lda, ldb, ldc;
+  int64_t stride_a, stride_b, stride_c;
+  int32_t batch;
+  int32_t tiles_m, tiles_n;
+  int32_t vec_a, vec_b;
+  float alpha, beta;
+  int32_t beta_zero;
+};
+
+// Global -> registers -> LDS for one operand tile (BMN x BK, 16-bit elements).
+// KMAJOR: k contiguous in global memory (A transposed / B not transposed).
+template <int BMN, int BK, int NT, bool KMAJOR>
+struct TileLoader16 {
+  static constexpr int V = 8;        // elements per 16-byte vector
+  static constexpr int S = BK + 8;   // LDS row stride (elements)
+  static constexpr int ELEMS = BMN * S;
+  static constexpr int NVEC = BMN * BK / V;
+  static_assert(NVEC % NT == 0, "tile must split evenly over the workgroup");
+  static constexpr int NV = NVEC / NT;
+  static constexpr int PER_ROW = KMAJOR ? (BK / V) : (BMN / V);
+
+  u16x8 reg[NV];
+
+  __device__ inline void load_fast(const uint16_t* __restrict__ x, int64_t ld, int64_t mn0, int64_t k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / PER_ROW;
+      const int col = (v % PER_ROW) * V;
+      const uint16_t* p = KMAJOR ? (x + (k0 + col) + (mn0 + row) * ld) : (x + (mn0 + col) + (k0 + row) * ld);
+      reg[i] = *reinterpret_cast<const u16x8*>(p);
+    }
+  }
+
+  // Element loads: rows/columns past the edge re-read the last valid one (they
+  // feed only unstored C elements); k past the end contributes exact zeros.
+  __device__ inline void load_edge(const uint16_t* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim,
+                                   int64_t k0, int64_t k_end, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / PER_ROW;
+      const int col = (v % PER_ROW) * V;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        int64_t mn = mn0 + (KMAJOR ? row : col + e);
+        const int64_t kk = k0 + (KMAJOR ? col + e : row);
+        mn = mn < mn_lim ? mn : (mn_lim - 1);
+        const bool live = kk < k_end;
+        const int64_t ks = live ? kk : (k_end - 1);
+        const uint16_t val = KMAJOR ? x[ks + mn * ld] : x[mn + ks * ld];
+        reg[i][e] = live ? val : uint16_t(0);
+      }
+    }
+  }
+
+  __device__ inline void store(SBAMD_LDS uint16_t* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / PER_ROW;
+      const int col = (v % PER_ROW) * V;
+      if (KMAJOR) {
+        *reinterpret_cast<SBAMD_LDS u16x8*>(lds + row * S + col) = reg[i];
+      } else {
+        // the vector runs along mn: transpose on the way in, one element per row
+#pragma unroll
+        for (int e = 0; e < V; ++e) lds[(col + e) * S + row] = reg[i][e];
+      }
+    }
+  }
+};
+
+template <typename Tag, typename TOut, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs16<TOut> g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  static_assert(MI >= 1 && NI >= 1 && BK % 16 == 0, "tile shape");
+  using LoadA = TileLoader16<BM, BK, NT, TA>;
+  using LoadB = TileLoader16<BN, BK, NT, !TB>;
+  constexpr int SA = LoadA::S, SB = LoadB::S;
+  constexpr int A_ELEMS = LoadA::ELEMS, B_ELEMS = LoadB::ELEMS;
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SBAMD_LDS uint16_t* smem = (SBAMD_LDS uint16_t*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = logical / ntiles;
+  int tm, tn;
+  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
+  const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
+  const uint16_t* a = g.a + int64_t(z) * g.stride_a;
+  const uint16_t* b = g.b + int64_t(z) * g.stride_b;
+  TOut* c = g.c + int64_t(z) * g.stride_c;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  LoadA la;
+  LoadB lb;
+  const bool fast = (m0 + BM <= g.m) && (n0 + BN <= g.n) && g.vec_a && g.vec_b;
+  const int nk = int((g.k + BK - 1) / BK);
+  const int frag_mn = lane & 31, frag_h = lane >> 5;
+  const int a_row = wm * WTM + frag_mn, b_row = wn * WTN + frag_mn;
+
+  auto load_tile = [&](int kt) {
+    const int64_t k0 = int64_t(kt) * BK;
+    if (fast && k0 + BK <= g.k) {
+      la.load_fast(a, g.lda, m0, k0, tid);
+      lb.load_fast(b, g.ldb, n0, k0, tid);
+    } else {
+      la.load_edge(a, g.lda, m0, g.m, k0, g.k, tid);
+      lb.load_edge(b, g.ldb, n0, g.n, k0, g.k, tid);
+    }
+  };
+
+  if (nk > 0) {
+    load_tile(0);
+    la.store(smem, tid);
+    lb.store(smem + A_ELEMS, tid);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const SBAMD_LDS uint16_t* as = smem + (kt & 1) * STAGE;
+    const SBAMD_LDS uint16_t* bs = as + A_ELEMS;
+    const bool more = kt + 1 < nk;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      u16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        fa[i] = *reinterpret_cast<const SBAMD_LDS u16x8*>(as + (a_row + i * 32) * SA + 16 * s + 8 * frag_h);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        fb[j] = *reinterpret_cast<const SBAMD_LDS u16x8*>(bs + (b_row + j * 32) * SB + 16 * s + 8 * frag_h);
+      // op0 carries the N index, op1 the M index: a lane ends up with one M index
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = Mfma16<Tag>::mma(fb[j], fa[i], acc[i][j]);
+    }
+    if (more) {
+      SBAMD_LDS uint16_t* nxt = smem + ((kt + 1) & 1) * STAGE;
+      la.store(nxt, tid);
+      lb.store(nxt + A_ELEMS, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue in fp32: out = alpha*acc (+ beta*C), rounded once to the output type
+  const bool read_c = !g.beta_zero;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int64_t mm = m0 + a_row + i * 32;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t nn = n0 + wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_h;
+        if (mm < g.m && nn < g.n) {
+          TOut* p = c + mm + nn * g.ldc;
+          float out = g.alpha * acc[i][j][r];
+          if (read_c) {
+            const float bc = g.beta * load_out(p);
+            out = out + bc;
+          }
+          store_out(p, out);
+        }
+      }
+    }
+  }
+}
+
+// C = beta * C for 16-bit output (alpha == 0 path): multiply in fp32, round once.
+__global__ void __launch_bounds__(256)
+    scale_matrix16_kernel(uint16_t* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride, int64_t batch,
+                          float beta, int assign_zero) {
+  const int64_t per = rows * cols;
+  const int64_t gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= per * batch) return;
+  const int64_t z = gid / per;
+  const int64_t idx = gid - z * per;
+  uint16_t* p = c + z * stride + (idx % rows) + (idx / rows) * ld;
+  if (assign_zero) *p = 0;
+  else store_out(p, beta * load_out(p));
+}
+
+}  // namespace sbamd

@@ -56,30 +56,80 @@ struct DeviceGuard {
   }
 };
 
-template <typename TOut>
-hipError_t scale_c(Handle* h, TOut* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride,
-                   int64_t batch, TOut beta, bool assign_zero);
-template <>
-hipError_t scale_c<float>(Handle* h, float* c, int64_t rows, int64_t cols, int64_t ld,
-                          int64_t stride, int64_t batch, float beta, bool assign_zero) {
-  return run_scale_f32(h, c, rows, cols, ld, stride, batch, beta, assign_zero);
-}
-template <>
-hipError_t scale_c<double>(Handle* h, double* c, int64_t rows, int64_t cols, int64_t ld,
-                           int64_t stride, int64_t batch, double beta, bool assign_zero) {
-  return run_scale_f64(h, c, rows, cols, ld, stride, batch, beta, assign_zero);
-}
+// One policy per instantiated type pair (src/interface/blas3/gemm.cpp.in:33-137
+// plus bfloat16 -> float): storage types, the scalar type alpha/beta are held
+// in, and the back end that serves it.
+struct PolicyS {
+  using in_t = float;
+  using out_t = float;
+  using scal_t = float;
+  static hipError_t run(Handle* h, const Problem<float, float>& p, float, float) { return run_gemm_f32(h, p); }
+  static hipError_t scale(Handle* h, float* c, int64_t r, int64_t n, int64_t ld, int64_t st, int64_t b, float beta,
+                          bool z) {
+    return run_scale_f32(h, c, r, n, ld, st, b, beta, z);
+  }
+};
+struct PolicyD {
+  using in_t = double;
+  using out_t = double;
+  using scal_t = double;
+  static hipError_t run(Handle* h, const Problem<double, double>& p, double, double) { return run_gemm_f64(h, p); }
+  static hipError_t scale(Handle* h, double* c, int64_t r, int64_t n, int64_t ld, int64_t st, int64_t b,
+                          double beta, bool z) {
+    return run_scale_f64(h, c, r, n, ld, st, b, beta, z);
+  }
+};
+struct PolicyH {  // half -> half
+  using in_t = uint16_t;
+  using out_t = uint16_t;
+  using scal_t = float;
+  static hipError_t run(Handle* h, const Problem<uint16_t, uint16_t>& p, float al, float be) {
+    return run_gemm_h(h, p, al, be);
+  }
+  static hipError_t scale(Handle* h, uint16_t* c, int64_t r, int64_t n, int64_t ld, int64_t st, int64_t b,
+                          float beta, bool z) {
+    return run_scale_f16(h, c, r, n, ld, st, b, beta, z);
+  }
+};
+struct PolicyHS {  // half -> float
+  using in_t = uint16_t;
+  using out_t = float;
+  using scal_t = float;
+  static hipError_t run(Handle* h, const Problem<uint16_t, float>& p, float al, float be) {
+    return run_gemm_hs(h, p, al, be);
+  }
+  static hipError_t scale(Handle* h, float* c, int64_t r, int64_t n, int64_t ld, int64_t st, int64_t b, float beta,
+                          bool z) {
+    return run_scale_f32(h, c, r, n, ld, st, b, beta, z);
+  }
+};
+struct PolicyBS : PolicyHS {  // bfloat16 -> float
+  static hipError_t run(Handle* h, const Problem<uint16_t, float>& p, float al, float be) {
+    return run_gemm_bs(h, p, al, be);
+  }
+};
 
-inline hipError_t run_backend(Handle* h, const Problem<float, float>& p) { return run_gemm_f32(h, p); }
-inline hipError_t run_backend(Handle* h, const Problem<double, double>& p) { return run_gemm_f64(h, p); }
+// Problem<> carries alpha/beta in the output type for the float/double back
+// ends; the 16-bit back ends take them as separate floats.
+template <typename TOut, typename TScal>
+struct scalar_slot {
+  static TOut put(TScal v) { return TOut(v); }
+};
+template <>
+struct scalar_slot<uint16_t, float> {
+  static uint16_t put(float) { return 0; }
+};
 
 // The reference's _gemm_backend (src/interface/gemm_interface.hpp:102-185),
 // in the same order: alpha == 0 first, then the trans flags, then the strides.
-template <typename TIn, typename TOut>
+template <typename P>
 int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t n, int64_t k,
-                 TOut alpha, const TIn* a, int64_t lda, int64_t stride_a, const TIn* b,
-                 int64_t ldb, int64_t stride_b, TOut beta, TOut* c, int64_t ldc,
-                 int64_t stride_c, int64_t batch, int batch_type) {
+                 typename P::scal_t alpha, const typename P::in_t* a, int64_t lda, int64_t stride_a,
+                 const typename P::in_t* b, int64_t ldb, int64_t stride_b, typename P::scal_t beta,
+                 typename P::out_t* c, int64_t ldc, int64_t stride_c, int64_t batch, int batch_type) {
+  using TIn = typename P::in_t;
+  using TOut = typename P::out_t;
+  using TScal = typename P::scal_t;
   if (!hh) return SBAMD_INVALID_HANDLE;
   Handle* h = &hh->impl;
   if (m < 0 || n < 0 || k < 0 || batch < 0 || lda < 0 || ldb < 0 || ldc < 0) return SBAMD_INVALID_VALUE;
@@ -90,7 +140,7 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   h->last_depth = 1;
   h->last_k_chunk = k;
 
-  if (alpha == TOut(0)) {
+  if (alpha == TScal(0)) {
     // gemm_interface.hpp:112-139.  size_c == stride_c picks a whole-buffer
     // scale; with ldc == m it is the vector _scal, whose zero factor stores
     // zeros (blas1_interface.hpp:444-448); every other route is _scal_matrix,
@@ -103,15 +153,15 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
       // Interleaved items share every column: element (r, c) of item b sits
       // at c*ldc*batch + r*batch + b, so the m x n windows of all items form
       // one (m*batch) x n window with leading dimension ldc*batch.
-      if (!(beta == TOut(1))) e = scale_c<TOut>(h, c, m * batch, n, ldc * batch, 0, 1, beta, false);
+      if (!(beta == TScal(1))) e = P::scale(h, c, m * batch, n, ldc * batch, 0, 1, beta, false);
     } else if (size_c == stride_c) {
       if (ldc == m) {
-        e = scale_c<TOut>(h, c, size_c * batch, 1, size_c * batch, 0, 1, beta, beta == TOut(0));
-      } else if (!(beta == TOut(1))) {
-        e = scale_c<TOut>(h, c, m, n * batch, ldc, 0, 1, beta, false);
+        e = P::scale(h, c, size_c * batch, 1, size_c * batch, 0, 1, beta, beta == TScal(0));
+      } else if (!(beta == TScal(1))) {
+        e = P::scale(h, c, m, n * batch, ldc, 0, 1, beta, false);
       }
-    } else if (!(beta == TOut(1))) {
-      e = scale_c<TOut>(h, c, m, n, ldc, stride_c, batch, beta, false);
+    } else if (!(beta == TScal(1))) {
+      e = P::scale(h, c, m, n, ldc, stride_c, batch, beta, false);
     }
     return e == hipSuccess ? SBAMD_OK : fail_hip(h, e, "scale launch");
   }
@@ -141,8 +191,8 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   p.m = m;
   p.n = n;
   p.k = k;
-  p.alpha = alpha;
-  p.beta = beta;
+  p.alpha = scalar_slot<TOut, TScal>::put(alpha);
+  p.beta = scalar_slot<TOut, TScal>::put(beta);
   p.a = a;
   p.lda = lda;
   p.stride_a = stride_a;
@@ -153,26 +203,28 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   p.ldc = ldc;
   p.stride_c = stride_c;
   p.batch = batch;
-  p.beta_zero = (beta == TOut(0));  // gemm_interface.hpp:92 (isZero)
+  p.beta_zero = (beta == TScal(0));  // gemm_interface.hpp:92 (isZero)
   // One item has the same addresses in both layouts, so it takes the strided kernels.
   p.interleaved = batch_type == SBAMD_BATCH_INTERLEAVED && batch > 1;
-  hipError_t e = run_backend(h, p);
+  hipError_t e = P::run(h, p, alpha, beta);
+  if (e == hipErrorNotSupported) return SBAMD_NOT_SUPPORTED;
   return e == hipSuccess ? SBAMD_OK : fail_hip(h, e, "gemm launch");
 }
 
 // _gemm_batched's default strides (gemm_interface.hpp:213-219).
-template <typename TIn, typename TOut>
+template <typename P>
 int gemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
-                 TOut alpha, const TIn* a, int64_t lda, const TIn* b, int64_t ldb, TOut beta,
-                 TOut* c, int64_t ldc, int64_t batch, int batch_type) {
+                 typename P::scal_t alpha, const typename P::in_t* a, int64_t lda, const typename P::in_t* b,
+                 int64_t ldb, typename P::scal_t beta, typename P::out_t* c, int64_t ldc, int64_t batch,
+                 int batch_type) {
   int64_t sa = 0, sb = 0, sc = 0;
   if (batch_type == SBAMD_BATCH_STRIDED) {
     sa = (std::tolower(static_cast<unsigned char>(transa)) != 'n') ? m * lda : k * lda;
     sb = (std::tolower(static_cast<unsigned char>(transb)) != 'n') ? ldb * k : n * ldb;
     sc = ldc * n;
   }
-  return gemm_backend<TIn, TOut>(h, transa, transb, m, n, k, alpha, a, lda, sa, b, ldb, sb, beta, c,
-                                 ldc, sc, batch, batch_type);
+  return gemm_backend<P>(h, transa, transb, m, n, k, alpha, a, lda, sa, b, ldb, sb, beta, c, ldc, sc, batch,
+                         batch_type);
 }
 
 }  // namespace
@@ -374,28 +426,28 @@ int sbamd_sgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n
                 float alpha, const float* a, int64_t lda, const float* b, int64_t ldb, float beta,
                 float* c, int64_t ldc) {
   // blas::_gemm: strides 0, batch 1, strided (gemm_interface.hpp:194-197)
-  return gemm_backend<float, float>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c,
+  return gemm_backend<PolicyS>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c,
                                     ldc, 0, 1, SBAMD_BATCH_STRIDED);
 }
 
 int sbamd_dgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
                 double alpha, const double* a, int64_t lda, const double* b, int64_t ldb,
                 double beta, double* c, int64_t ldc) {
-  return gemm_backend<double, double>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta,
+  return gemm_backend<PolicyD>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta,
                                       c, ldc, 0, 1, SBAMD_BATCH_STRIDED);
 }
 
 int sbamd_sgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
                         float alpha, const float* a, int64_t lda, const float* b, int64_t ldb,
                         float beta, float* c, int64_t ldc, int64_t batch, int batch_type) {
-  return gemm_batched<float, float>(h, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc,
+  return gemm_batched<PolicyS>(h, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc,
                                     batch, batch_type);
 }
 
 int sbamd_dgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
                         double alpha, const double* a, int64_t lda, const double* b, int64_t ldb,
                         double beta, double* c, int64_t ldc, int64_t batch, int batch_type) {
-  return gemm_batched<double, double>(h, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c,
+  return gemm_batched<PolicyD>(h, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c,
                                       ldc, batch, batch_type);
 }
 
@@ -404,7 +456,7 @@ int sbamd_sgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int6
                                 int64_t stride_a, const float* b, int64_t ldb, int64_t stride_b,
                                 float beta, float* c, int64_t ldc, int64_t stride_c,
                                 int64_t batch) {
-  return gemm_backend<float, float>(h, transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb,
+  return gemm_backend<PolicyS>(h, transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb,
                                     stride_b, beta, c, ldc, stride_c, batch, SBAMD_BATCH_STRIDED);
 }
 
@@ -413,38 +465,54 @@ int sbamd_dgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int6
                                 int64_t stride_a, const double* b, int64_t ldb, int64_t stride_b,
                                 double beta, double* c, int64_t ldc, int64_t stride_c,
                                 int64_t batch) {
-  return gemm_backend<double, double>(h, transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb,
+  return gemm_backend<PolicyD>(h, transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb,
                                       stride_b, beta, c, ldc, stride_c, batch, SBAMD_BATCH_STRIDED);
 }
 
 /* ------------------------------------------------- half / bfloat16 storage */
 
-int sbamd_hgemm(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float, const uint16_t*,
-                int64_t, const uint16_t*, int64_t, float, uint16_t*, int64_t) {
-  return SBAMD_NOT_SUPPORTED;
+// alpha / beta of the half -> half pair have the output type in the reference
+// (gemm.cpp.in:33-39): round them to binary16 before use.
+static inline float to_half_precision(float v) { return float(_Float16(v)); }
+
+int sbamd_hgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k, float alpha,
+                const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, float beta, uint16_t* c,
+                int64_t ldc) {
+  return gemm_backend<PolicyH>(h, transa, transb, m, n, k, to_half_precision(alpha), a, lda, 0, b, ldb, 0,
+                               to_half_precision(beta), c, ldc, 0, 1, SBAMD_BATCH_STRIDED);
 }
-int sbamd_hsgemm(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float, const uint16_t*,
-                 int64_t, const uint16_t*, int64_t, float, float*, int64_t) {
-  return SBAMD_NOT_SUPPORTED;
+int sbamd_hsgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k, float alpha,
+                 const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, float beta, float* c,
+                 int64_t ldc) {
+  return gemm_backend<PolicyHS>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c, ldc, 0, 1,
+                                SBAMD_BATCH_STRIDED);
 }
-int sbamd_bsgemm(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float, const uint16_t*,
-                 int64_t, const uint16_t*, int64_t, float, float*, int64_t) {
-  return SBAMD_NOT_SUPPORTED;
+int sbamd_bsgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k, float alpha,
+                 const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, float beta, float* c,
+                 int64_t ldc) {
+  return gemm_backend<PolicyBS>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c, ldc, 0, 1,
+                                SBAMD_BATCH_STRIDED);
 }
-int sbamd_hgemm_strided_batched(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float,
-                                const uint16_t*, int64_t, int64_t, const uint16_t*, int64_t,
-                                int64_t, float, uint16_t*, int64_t, int64_t, int64_t) {
-  return SBAMD_NOT_SUPPORTED;
+int sbamd_hgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                                float alpha, const uint16_t* a, int64_t lda, int64_t stride_a, const uint16_t* b,
+                                int64_t ldb, int64_t stride_b, float beta, uint16_t* c, int64_t ldc,
+                                int64_t stride_c, int64_t batch) {
+  return gemm_backend<PolicyH>(h, transa, transb, m, n, k, to_half_precision(alpha), a, lda, stride_a, b, ldb,
+                               stride_b, to_half_precision(beta), c, ldc, stride_c, batch, SBAMD_BATCH_STRIDED);
 }
-int sbamd_hsgemm_strided_batched(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float,
-                                 const uint16_t*, int64_t, int64_t, const uint16_t*, int64_t,
-                                 int64_t, float, float*, int64_t, int64_t, int64_t) {
-  return SBAMD_NOT_SUPPORTED;
+int sbamd_hsgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                                 float alpha, const uint16_t* a, int64_t lda, int64_t stride_a, const uint16_t* b,
+                                 int64_t ldb, int64_t stride_b, float beta, float* c, int64_t ldc,
+                                 int64_t stride_c, int64_t batch) {
+  return gemm_backend<PolicyHS>(h, transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb, stride_b, beta, c, ldc,
+                                stride_c, batch, SBAMD_BATCH_STRIDED);
 }
-int sbamd_bsgemm_strided_batched(sbamd_handle_t, char, char, int64_t, int64_t, int64_t, float,
-                                 const uint16_t*, int64_t, int64_t, const uint16_t*, int64_t,
-                                 int64_t, float, float*, int64_t, int64_t, int64_t) {
-  return SBAMD_NOT_SUPPORTED;
+int sbamd_bsgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                                 float alpha, const uint16_t* a, int64_t lda, int64_t stride_a, const uint16_t* b,
+                                 int64_t ldb, int64_t stride_b, float beta, float* c, int64_t ldc,
+                                 int64_t stride_c, int64_t batch) {
+  return gemm_backend<PolicyBS>(h, transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb, stride_b, beta, c, ldc,
+                                stride_c, batch, SBAMD_BATCH_STRIDED);
 }
 
 }  // extern "C"

@@ -55,6 +55,14 @@ struct Problem {
 hipError_t run_gemm_f32(Handle* h, const Problem<float, float>& p);
 hipError_t run_gemm_f64(Handle* h, const Problem<double, double>& p);
 
+// 16-bit storage (bit patterns): half -> half, half -> float, bfloat16 -> float.
+// alpha / beta arrive as float (already rounded to the output type by the caller).
+hipError_t run_gemm_h(Handle* h, const Problem<uint16_t, uint16_t>& p, float alpha, float beta);
+hipError_t run_gemm_hs(Handle* h, const Problem<uint16_t, float>& p, float alpha, float beta);
+hipError_t run_gemm_bs(Handle* h, const Problem<uint16_t, float>& p, float alpha, float beta);
+hipError_t run_scale_f16(Handle* h, uint16_t* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride,
+                         int64_t batch, float beta, bool assign_zero);
+
 // C = beta * C over `batch` windows of rows x cols (alpha == 0 path).
 hipError_t run_scale_f32(Handle* h, float* c, int64_t rows, int64_t cols, int64_t ld,
                          int64_t stride, int64_t batch, float beta, bool assign_zero);

@@ -144,3 +144,17 @@ def test_argument_errors(sb_handle):
     # batch == 1 skips the stride checks (gemm_interface.hpp:158)
     sb._gemm_strided_batched(h, "C", "T", 4, 4, 4, 1.0, buf, 4, -1, buf, 4, -1, 0.0, buf, 4, 0, 1)
     h.wait()
+
+
+def test_cpp_sample_through_compat_header():
+    """samples/gemm.cpp (the reference's sample shape over include/portblas_compat.hpp)."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "samples", "gemm_sample")
+    assert os.path.exists(exe), "build it with `make -C samples` (or __graft_entry__.build())"
+    for args in ([], ["1024"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "PASS" in out.stdout

@@ -1,0 +1,174 @@
+"""GPU parity tests for the 16-bit storage pairs: half -> half, half -> float
+(the reference's instantiations, cmake/CmakeFunctionHelper.cmake:148-159) and
+bfloat16 -> float.
+
+Method: the reference's reduced-precision test recipe
+(test/unittest/joint_matrix/joint_matrix_common.hpp:93-111, test/blas_test.hpp:225-244):
+make every input exactly representable in the storage type, then compare with a
+float GEMM of the same values.  Products of two 16-bit values are exact in fp32
+and the kernels accumulate in fp32, so:
+  * float outputs must pass the reference's FLOAT predicate against the oracle's
+    fp32 chain (float_comparison.hpp:100-143) and stay inside the fp32
+    accumulation bound  |got - exact| <= (K + 2) * 2^-24 * (|alpha| sum|a||b| + |beta||c|);
+  * half outputs add one rounding to binary16 (2^-11 relative) and must pass the
+    reference's HALF predicate (float_comparison.hpp:123-158).
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import oracle
+import sycl_blas_amd as sb
+from sycl_blas_amd import DeviceBuffer, _lib, helper
+
+from common import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def to_bf16_bits(x):
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def from_bf16_bits(b):
+    return (b.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def make_inputs(rng, count, storage):
+    """(bit patterns as stored on the device, the same values as float32)."""
+    x = rng.uniform(-2.0, 5.0, count).astype(np.float32)
+    if storage == "float16":
+        h = x.astype(np.float16)
+        return h.view(np.uint16), h.astype(np.float32)
+    bits = to_bf16_bits(x)
+    return bits, from_bf16_bits(bits)
+
+
+def run_case(h, pair, m, n, k, ta, tb, alpha, beta, ldm=1, offset=0, batch=1, family=_lib.KERNEL_AUTO):
+    storage, out_name = pair
+    rng = seeded("half", pair, m, n, k, ta, tb, alpha, beta, ldm, offset, batch)
+    lda = (k if ta != "n" else m) * ldm
+    ldb = (n if tb != "n" else k) * ldm
+    ldc = m * ldm
+    sa, sb_, sc = m * k * ldm, k * n * ldm, m * n * ldm
+    a_bits, a_f = make_inputs(rng, batch * sa + offset, storage)
+    b_bits, b_f = make_inputs(rng, batch * sb_ + offset, storage)
+    if out_name == "float16":
+        c_h = rng.uniform(-2.0, 5.0, batch * sc + offset).astype(np.float16)
+        c_dev, c_f = c_h.view(np.uint16).copy(), c_h.astype(np.float32)
+    else:
+        c_f = rng.uniform(-2.0, 5.0, batch * sc + offset).astype(np.float32)
+        c_dev = c_f.copy()
+
+    # oracle: fp32 chain on the same values (what the reference's test compares with)
+    want = c_f.copy()
+    st = oracle.gemm_backend(ta, tb, m, n, k, alpha, a_f, lda, sa, b_f, ldb, sb_, beta, want, ldc, sc, batch=batch,
+                             a_off=offset, b_off=offset, c_off=offset)
+    assert st == 0
+
+    h.set_kernel(family)
+    a_g = helper.allocate(h, storage, a_bits.size)
+    b_g = helper.allocate(h, storage, b_bits.size)
+    c_g = helper.allocate(h, out_name, c_dev.size)
+    deps = [helper.copy_to_device(h, a_bits, a_g), helper.copy_to_device(h, b_bits, b_g),
+            helper.copy_to_device(h, c_dev, c_g)]
+    if batch == 1:
+        ev = sb._gemm(h, ta, tb, m, n, k, alpha, a_g + offset, lda, b_g + offset, ldb, beta, c_g + offset, ldc, deps)
+    else:
+        ev = sb._gemm_batched(h, ta, tb, m, n, k, alpha, a_g + offset, lda, b_g + offset, ldb, beta, c_g + offset,
+                              ldc, batch, sb.gemm_batch_type_t.strided, deps)
+    h.wait(ev)
+    got_dev = np.empty_like(c_dev)
+    h.wait(helper.copy_to_host(h, c_g, got_dev))
+    for buf in (a_g, b_g, c_g):
+        helper.deallocate(buf)
+    h.set_kernel(_lib.KERNEL_AUTO)
+
+    what = f"{storage}->{out_name} {m}x{n}x{k} {ta}{tb} a={alpha} b={beta} ld*{ldm} off={offset} batch={batch}"
+    # fp32 accumulation bound against the long-double result, item by item
+    for z in range(batch):
+        truth, mag = oracle.gemm_truth(ta != "n", tb != "n", m, n, k, alpha,
+                                       a_f[offset + z * sa:].astype(np.float64), lda,
+                                       b_f[offset + z * sb_:].astype(np.float64), ldb, beta,
+                                       c_f[offset + z * sc:].astype(np.float64), ldc)
+        idx = (offset + z * sc + np.arange(m)[:, None] + np.arange(n)[None, :] * ldc).T.ravel()  # column-major order
+        if out_name == "float16":
+            got = got_dev.view(np.float16).astype(np.float64)[idx]
+            bound = (k + 2) * 2.0 ** -24 * mag + 2.0 ** -11 * np.abs(truth) + 1e-7
+        else:
+            got = got_dev.astype(np.float64)[idx]
+            bound = (k + 2) * 2.0 ** -24 * mag + 1e-30
+        err = np.abs(got - truth)
+        assert (err <= bound).all(), f"{what}: error {err.max():.3e} beyond the fp32 accumulation bound"
+    if out_name == "float16":
+        got_all = got_dev.view(np.float16).astype(np.float32)
+        assert oracle.compare_vectors(got_all, want.astype(np.float16).astype(np.float32), "float16") == -1, what
+        # nothing outside the m x n windows may change
+        mask = np.ones(got_all.size, bool)
+        for z in range(batch):
+            mask[(offset + z * sc + np.arange(m)[:, None] + np.arange(n)[None, :] * ldc).ravel()] = False
+        assert np.array_equal(got_dev[mask], c_dev[mask]), what
+    else:
+        assert oracle.compare_vectors(got_dev, want, "float32") == -1, what
+        mask = np.ones(got_dev.size, bool)
+        for z in range(batch):
+            mask[(offset + z * sc + np.arange(m)[:, None] + np.arange(n)[None, :] * ldc).ravel()] = False
+        assert np.array_equal(got_dev[mask], c_dev[mask]), what
+
+
+PAIRS = [("float16", "float16"), ("float16", "float32"), ("bfloat16", "float32")]
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_small_grids(sb_handle, pair):
+    # blas3_gemm_test.cpp:29-84 shapes
+    for m, n, k, ta, tb in itertools.product([11, 16, 32], [11, 32], [16, 17], "nt", "nt"):
+        run_case(sb_handle, pair, m, n, k, ta, tb, 1.5, 1.5)
+    for m, n, ta, tb in itertools.product([11, 32], [11, 32], "nt", "nt"):
+        run_case(sb_handle, pair, m, n, 17, ta, tb, 1.5, 0.0, ldm=2)
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_large_offsets_and_batches(sb_handle, pair):
+    # blas3_gemm_test.cpp:105-141 and blas3_gemm_batched_test.cpp:29-46 shapes (a slice)
+    for m, n, k, ta, tb in itertools.product([253, 1024], [257], [253, 511], "nt", "nt"):
+        run_case(sb_handle, pair, m, n, k, ta, tb, 1.0, 1.0)
+    for off, m, k in itertools.product([1, 10], [16, 63], [17, 63]):
+        run_case(sb_handle, pair, m, 63, k, "n", "n", 1.0, 1.0, ldm=2, offset=off)
+    for off, ta, tb in itertools.product([0, 33], "nt", "nt"):
+        run_case(sb_handle, pair, 63, 128, 128, ta, tb, 3.0, 7.0, offset=off, batch=5)
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+@pytest.mark.parametrize("family", ["LARGE", "SMALL"])
+def test_both_tile_families(sb_handle, pair, family):
+    fam = getattr(_lib, "KERNEL_" + family)
+    for (m, n, k), ta, tb in itertools.product([(1, 1, 1), (129, 127, 70), (256, 128, 192), (200, 260, 133)], "nt", "nt"):
+        run_case(sb_handle, pair, m, n, k, ta, tb, 1.5, 0.5, family=fam)
+        run_case(sb_handle, pair, m, n, k, ta, tb, -2.0, 0.0, ldm=2, offset=8, family=fam)
+
+
+def test_alpha_zero_and_beta_zero_on_half_output(sb_handle):
+    h = sb_handle
+    m = n = 16
+    c = np.arange(m * n, dtype=np.float16)
+    c[7] = np.nan
+    a_g = helper.allocate(h, "float16", m * n)
+    c_g = helper.allocate(h, "float16", m * n)
+    helper.copy_to_device(h, np.ones(m * n, np.float16).view(np.uint16), a_g)
+    out = np.empty(m * n, np.uint16)
+    # alpha == 0 multiplies C by beta in place; the trans flags are not looked at
+    helper.copy_to_device(h, c.view(np.uint16), c_g)
+    sb._gemm(h, "x", "y", m, n, 4, 0.0, a_g, m, a_g, m, 2.0, c_g, m)
+    h.wait(helper.copy_to_host(h, c_g, out))
+    want = (c.astype(np.float32) * 2).astype(np.float16)
+    assert np.array_equal(out.view(np.float16), want, equal_nan=True)
+    # beta == 0 never reads C: the NaN does not survive
+    helper.copy_to_device(h, c.view(np.uint16), c_g)
+    sb._gemm(h, "n", "n", m, n, 16, 1.0, a_g, m, a_g, m, 0.0, c_g, m)
+    h.wait(helper.copy_to_host(h, c_g, out))
+    assert (out.view(np.float16) == 16).all()
+    with pytest.raises(ValueError, match="invalid _TransB"):
+        sb._gemm(h, "n", "q", m, n, 16, 1.0, a_g, m, a_g, m, 0.0, c_g, m)

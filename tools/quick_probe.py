@@ -113,6 +113,24 @@ def main():
         for kk in (65536, 1 << 20, 1 << 22):
             bench(h, np.float32, 256, 256, kk, "n", "n", _lib.KERNEL_AUTO, reps=3)
             print("   splitk cut", h.last_splitk(), flush=True)
+        for name in ("float16", "bfloat16"):
+            for n_ in (4096, 8192):
+                a_g = helper.allocate(h, name, n_ * n_)
+                b_g = helper.allocate(h, name, n_ * n_)
+                c_g = helper.allocate(h, "float32", n_ * n_)
+                helper.fill_uniform(h, a_g, n_ * n_, 1)
+                helper.fill_uniform(h, b_g, n_ * n_, 2)
+                for ta, tb in (("n", "n"), ("n", "t"), ("t", "n")):
+                    run = lambda: sb._gemm(h, ta, tb, n_, n_, n_, 1.0, a_g, n_, b_g, n_, 0.0, c_g, n_)
+                    run(); h.wait()
+                    e0 = h.record_event()
+                    for _ in range(3):
+                        run()
+                    e1 = h.record_event(); e1.wait()
+                    ms = e0.elapsed_ms(e1) / 3
+                    print(f"BENCH {name}->f32 {n_}^3 {ta}{tb}: {ms:.3f} ms {2.0 * n_ ** 3 / ms / 1e9:.1f} TFLOP/s", flush=True)
+                for buf in (a_g, b_g, c_g):
+                    helper.deallocate(buf)
     h.close()
 
 
