@@ -94,6 +94,71 @@ def device_time_ms(sb, handle, fn, reps, warm=2):
     return e0.elapsed_ms(e1) / reps
 
 
+def side_measurements(torch, sb, handle, size):
+    """Untimed-region companions of the headline number (device time from HIP events):
+    the other 8192^3 variants of config #2, config #3 (strided-batched 64^3 x 4096, HBM-bound),
+    config #4 (256 x 256 x 4194304 split-K) and the bf16-input variant of config #5's kernel."""
+    from sycl_blas_amd import helper
+
+    extras = {}
+    for dt, tr in (("f32", "nt"), ("f64", "nn"), ("f64", "nt")):
+        o = Operands(torch, sb, handle, dt, tr[0], tr[1], size, size, size, 777)
+        ms = device_time_ms(sb, handle, lambda: o.run(sb, handle), 5)
+        tf = 2.0 * size ** 3 / ms / 1e9
+        extras[f"{dt}_{tr}_{size}"] = {"ms": round(ms, 4), "tflops": round(tf, 2),
+                                       "pct_mfma_peak": round(100 * tf / PEAK_TFLOPS[dt], 2)}
+        del o
+
+    # config #3: batch 4096 of 64x64x64, strides 4096 elements, beta = 0
+    bm, batch = 64, 4096
+    per = bm * bm
+    a = helper.allocate(handle, "float32", per * batch)
+    b = helper.allocate(handle, "float32", per * batch)
+    c = helper.allocate(handle, "float32", per * batch)
+    helper.fill_uniform(handle, a, per * batch, 31)
+    helper.fill_uniform(handle, b, per * batch, 32)
+    ms = device_time_ms(sb, handle, lambda: sb._gemm_strided_batched(handle, "n", "n", bm, bm, bm, 1.0, a, bm, per, b, bm,
+                                                                      per, 0.0, c, bm, per, batch), 20, warm=5)
+    nbytes = 3.0 * per * batch * 4  # (MK + KN + MN) * sizeof * batch
+    extras["sgemm_strided_batched_4096x64^3"] = {
+        "us": round(ms * 1e3, 2), "tflops": round(2.0 * bm ** 3 * batch / ms / 1e9, 2),
+        "algorithmic_GBps": round(nbytes / ms / 1e6, 1), "pct_hbm_peak": round(100 * nbytes / ms / 1e6 / PEAK_HBM_GBS, 2),
+        "bound": "hbm"}
+    for buf in (a, b, c):
+        helper.deallocate(buf)
+
+    # config #4: 256 x 256 x 4194304, NN (A 4 GiB, B 4 GiB)
+    m = n = 256
+    k = 1 << 22
+    a = helper.allocate(handle, "float32", m * k)
+    b = helper.allocate(handle, "float32", k * n)
+    c = helper.allocate(handle, "float32", m * n)
+    helper.fill_uniform(handle, a, m * k, 41)
+    helper.fill_uniform(handle, b, k * n, 42)
+    ms = device_time_ms(sb, handle, lambda: sb._gemm(handle, "n", "n", m, n, k, 1.0, a, m, b, k, 0.0, c, m), 3, warm=1)
+    depth, k_chunk = handle.last_splitk()
+    tf = 2.0 * m * n * k / ms / 1e9
+    extras["sgemm_tall_skinny_256x256x4194304"] = {
+        "ms": round(ms, 3), "tflops": round(tf, 2), "pct_mfma_peak": round(100 * tf / PEAK_TFLOPS["f32"], 2),
+        "algorithmic_GBps": round((m * k + k * n + m * n) * 4 / ms / 1e6, 1), "split_k": [depth, k_chunk]}
+    for buf in (a, b, c):
+        helper.deallocate(buf)
+
+    # bf16 inputs, fp32 output (kernel of config #5's bf16 variant), 8192^3 TN and NN
+    a = helper.allocate(handle, "bfloat16", size * size)
+    b = helper.allocate(handle, "bfloat16", size * size)
+    c = helper.allocate(handle, "float32", size * size)
+    helper.fill_uniform(handle, a, size * size, 51)
+    helper.fill_uniform(handle, b, size * size, 52)
+    for tr in ("tn", "nn"):
+        ms = device_time_ms(sb, handle, lambda: sb._gemm(handle, tr[0], tr[1], size, size, size, 1.0, a, size, b, size,
+                                                          0.0, c, size), 3, warm=1)
+        extras[f"bf16_f32out_{tr}_{size}"] = {"ms": round(ms, 4), "tflops": round(2.0 * size ** 3 / ms / 1e9, 1)}
+    for buf in (a, b, c):
+        helper.deallocate(buf)
+    return extras
+
+
 def cpu_baseline(dtype, ta, tb, size, seed):
     """The CPU restatement (oracle) timed on the host cores on a bounded sample:
     the first `cols` columns of C of the same product (same A, a column slab of B)."""
@@ -244,15 +309,7 @@ def main():
         }
 
         if not args.no_extras and world == 1:
-            extras = {}
-            for dt, tr in (("f32", "nt"), ("f64", "nn"), ("f64", "nt")):
-                o = Operands(torch, sb, handle, dt, tr[0], tr[1], size, size, size, 777)
-                ms = device_time_ms(sb, handle, lambda: o.run(sb, handle), 5)
-                tf = 2.0 * size ** 3 / ms / 1e9
-                extras[f"{dt}_{tr}_{size}"] = {"ms": round(ms, 4), "tflops": round(tf, 2),
-                                               "pct_peak": round(100 * tf / PEAK_TFLOPS[dt], 2)}
-                del o
-            out["extras"] = extras
+            out["extras"] = side_measurements(torch, sb, handle, size)
 
         if not args.no_cpu and world == 1:
             try:
