@@ -38,7 +38,11 @@ hipError_t launch_one(const GemmArgs<T>& g, int64_t nz, hipStream_t stream) {
   }
   const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * nz;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(K::NT), K::LDS_BYTES, stream, g);
+  // A K range that fits one K step never touches the second LDS buffer: ask for
+  // one stage only, which doubles the workgroups a compute unit can hold.
+  const int64_t k_span = g.split_k > 1 ? g.k_chunk : g.k;
+  const size_t lds = k_span <= BK ? K::LDS_BYTES / 2 : K::LDS_BYTES;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(K::NT), lds, stream, g);
   return hipGetLastError();
 }
 
@@ -95,11 +99,11 @@ template <typename T>
 struct Tiles;
 template <>
 struct Tiles<float> {
-  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 32;
+  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 32, ONESHOT_BK = 64;
 };
 template <>
 struct Tiles<double> {
-  static constexpr int LARGE_BK = 8, SMALL_BK = 8, HUGE_BK = 16;
+  static constexpr int LARGE_BK = 8, SMALL_BK = 8, HUGE_BK = 16, ONESHOT_BK = 64;
 };
 
 // The reference's tall-skinny predicate (amd_gpu.hpp:77-81).
@@ -214,6 +218,11 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     case SBAMD_KERNEL_HUGE:
       return launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(g, p.ta, p.tb, h->stream);
     case SBAMD_KERNEL_SMALL:
+      // Short K (the batched 64x64x64 class): stage the whole K range at once --
+      // one load burst, one barrier, no K loop -- so a CU overlaps the loads of
+      // some items with the matrix work of others.
+      if (p.k <= Tiles<T>::ONESHOT_BK && p.k > Tiles<T>::SMALL_BK)
+        return launch_tile<T, 64, 64, Tiles<T>::ONESHOT_BK, 2, 2, sizeof(T) == 4 ? 4 : 2>(g, p.ta, p.tb, h->stream);
       return launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(g, p.ta, p.tb, h->stream);
     case SBAMD_KERNEL_NAIVE:
       return launch_naive<T>(g, p.ta, p.tb, h->stream);

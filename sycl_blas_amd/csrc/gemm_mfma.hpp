@@ -29,6 +29,14 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // instruction (a generic pointer would fall back to flat loads).
 #define SBAMD_LDS __attribute__((address_space(3)))
 
+// Timing-only diagnostic (tools/ablate.hip): bits switch off parts of the
+// pipelined main loop so their cost can be read from the run time.  The
+// results of such a build are wrong by construction; the library is always
+// built with 0.   1: LDS stores  2: global loads  4: barrier  8: fragment reads
+#ifndef SBAMD_ABLATE
+#define SBAMD_ABLATE 0
+#endif
+
 // Arguments shared by every kernel in this file.  Pointers are typed in the
 // kernels; sizes are 64-bit so 65536 x 65536 operands index correctly.
 template <typename T>
@@ -131,18 +139,31 @@ struct TileLoader {
 
   T reg[NV][V];
 
-  // Interior tile, whole K step, 16-byte aligned: straight-line vector loads.
-  __device__ inline void load_fast(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t k0,
-                                   int tid) {
+  // Interior tile, whole K step, 16-byte aligned: straight-line vector loads
+  // through per-thread pointers that are set up once per workgroup and then
+  // only advanced by a uniform stride (address arithmetic per load and K step
+  // would otherwise steal issue slots from the matrix instructions).
+  const T* ptr[NV];
+
+  __device__ inline void init_fast(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t k0, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
-      const T* p = KMAJOR ? (x + (k0 + col) + (mn0 + row) * ld) : (x + (mn0 + col) + (k0 + row) * ld);
-      const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(p);
+      ptr[i] = KMAJOR ? (x + (k0 + col) + (mn0 + row) * ld) : (x + (mn0 + col) + (k0 + row) * ld);
+    }
+  }
+
+  // Load the tile the pointers address, then move them one K step on.
+  __device__ inline void load_fast(int64_t ld) {
+    const int64_t step = KMAJOR ? int64_t(BK) : int64_t(BK) * ld;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(ptr[i]);
 #pragma unroll
       for (int e = 0; e < V; ++e) reg[i][e] = vv[e];
+      ptr[i] += step;
     }
   }
 
@@ -366,7 +387,7 @@ struct GemmBody {
     constexpr int NM = K::MI * K::NI * M::GS;
 #pragma unroll
     for (int grp = 0; grp + 1 < K::NGRP; ++grp) {
-      fetch_group(as, bs, grp + 1, a_mn, b_mn, lane, fa[(grp + 1) & 1], fb[(grp + 1) & 1]);
+      if (!(SBAMD_ABLATE & 8)) fetch_group(as, bs, grp + 1, a_mn, b_mn, lane, fa[(grp + 1) & 1], fb[(grp + 1) & 1]);
       mma_group(fa[grp & 1], fb[grp & 1]);
     }
     // 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write
@@ -380,8 +401,8 @@ struct GemmBody {
       else if (n < NWRITE + NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       if (n % STRIDE == 0) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
     }
-    __syncthreads();
-    if (HAS_NEXT) fetch_group(nas, nbs, 0, a_mn, b_mn, lane, fa[0], fb[0]);
+    if (!(SBAMD_ABLATE & 4)) __syncthreads();
+    if (HAS_NEXT && !(SBAMD_ABLATE & 8)) fetch_group(nas, nbs, 0, a_mn, b_mn, lane, fa[0], fb[0]);
     mma_group(fa[(K::NGRP - 1) & 1], fb[(K::NGRP - 1) & 1]);
   }
 
@@ -396,13 +417,15 @@ struct GemmBody {
     SBAMD_LDS T* const buf0 = smem;
     SBAMD_LDS T* const buf1 = smem + K::STAGE_ELEMS;
 
-    la.load_fast(a, g.lda, m0, k_begin, tid);
-    lb.load_fast(b, g.ldb, n0, k_begin, tid);
+    la.init_fast(a, g.lda, m0, k_begin, tid);
+    lb.init_fast(b, g.ldb, n0, k_begin, tid);
+    la.load_fast(g.lda);
+    lb.load_fast(g.ldb);
     la.store(buf0, tid);
     lb.store(buf0 + K::A_ELEMS, tid);
     if (nfull > 1) {
-      la.load_fast(a, g.lda, m0, k_begin + BK, tid);
-      lb.load_fast(b, g.ldb, n0, k_begin + BK, tid);
+      la.load_fast(g.lda);
+      lb.load_fast(g.ldb);
     }
     __syncthreads();
     frag_a_t fa;
@@ -413,11 +436,14 @@ struct GemmBody {
     for (; kt + 2 < nfull; ++kt) {
       SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
       SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
-      la.store(nxt, tid);
-      lb.store(nxt + K::A_ELEMS, tid);
-      const int64_t k2 = k_begin + int64_t(kt + 2) * BK;
-      la.load_fast(a, g.lda, m0, k2, tid);
-      lb.load_fast(b, g.ldb, n0, k2, tid);
+      if (!(SBAMD_ABLATE & 1)) {
+        la.store(nxt, tid);
+        lb.store(nxt + K::A_ELEMS, tid);
+      }
+      if (!(SBAMD_ABLATE & 2)) {
+        la.load_fast(g.lda);
+        lb.load_fast(g.ldb);
+      }
       pipelined_step<true, NW, NL>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
     }
     if (kt + 1 < nfull) {  // last but one: nothing left to load
