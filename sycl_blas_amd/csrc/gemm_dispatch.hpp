@@ -172,12 +172,18 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   if (family == SBAMD_KERNEL_SPLITK) {
     // Tile for the partial products: the large tile once M and N fill it.
     const bool big = p.m > 64 && p.n > 64;
-    const int bm = big ? 128 : 64;
-    const int bk = big ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
-    const int64_t tiles_mn = ceil_div(p.m, bm) * ceil_div(p.n, bm);
-    // Cube depth: four workgroups per compute unit
-    // (src/operations/blas3/gemm_partial_local.hpp:191-199) unless pinned.
-    int64_t depth = h->kernel_param > 0 ? h->kernel_param : ceil_div(4 * int64_t(cus), tiles_mn);
+    // 256x128 once M fills it: A is then streamed by half as many tile columns.
+    const bool huge = p.m > 192 && p.n > 64 && !(sizeof(T) == 4 && p.ta && p.tb);
+    const int bm = huge ? 256 : big ? 128 : 64;
+    const int bn = big ? 128 : 64;
+    const int bk = huge ? Tiles<T>::HUGE_BK : big ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
+    const int64_t tiles_mn = ceil_div(p.m, bm) * ceil_div(p.n, bn);
+    // Cube depth: four workgroups per compute unit as in the reference
+    // (src/operations/blas3/gemm_partial_local.hpp:191-199); one per compute unit
+    // for the eight-wave 256x128 workgroups, which measured best at 256x256x4M
+    // (124 TFLOP/s at one per CU, 121 at four) -- unless pinned.
+    const int64_t per_cu = huge ? 1 : 4;
+    int64_t depth = h->kernel_param > 0 ? h->kernel_param : ceil_div(per_cu * int64_t(cus), tiles_mn);
     // The reference falls back to one final partial kernel for shallow K
     // (portblas_handle.hpp:323-331).
     if (h->kernel_param <= 0 && (depth == 1 || p.k <= 2048)) depth = 1;
@@ -196,8 +202,9 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       gp.k_chunk = k_chunk;
       gp.slice_stride = slice;
       gp.beta_zero = 1;
-      e = big ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream)
-              : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
+      e = huge  ? launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(gp, p.ta, p.tb, h->stream)
+          : big ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream)
+                : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
       if (e != hipSuccess) return e;
       const int64_t grid = ceil_div(slice, 256);
       hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)grid), dim3(256), 0, h->stream,

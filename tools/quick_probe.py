@@ -113,6 +113,9 @@ def main():
         for kk in (65536, 1 << 20, 1 << 22):
             bench(h, np.float32, 256, 256, kk, "n", "n", _lib.KERNEL_AUTO, reps=3)
             print("   splitk cut", h.last_splitk(), flush=True)
+        for depth in (64, 128, 256, 384, 512, 1024):
+            bench(h, np.float32, 256, 256, 1 << 22, "n", "n", _lib.KERNEL_SPLITK, reps=3, param=depth)
+            print("   splitk cut", h.last_splitk(), flush=True)
         for name in ("float16", "bfloat16"):
             for n_ in (4096, 8192):
                 a_g = helper.allocate(h, name, n_ * n_)
