@@ -10,10 +10,16 @@
 // 16-bit values are exact in fp32 and the sum is kept in fp32, so the result is
 // at least as accurate as the reference's; the output is rounded once at the end.
 //
-// Both operand tiles sit in LDS as [mn][BK + 8] images, k fastest: a lane's MFMA
-// fragment (8 consecutive k of one row) is then one 16-byte read, and the
-// 16-byte row padding makes the stride an odd number of 16-byte slots so the
-// 16 lanes of a ds_read_b128 group hit 16 different slots.
+// LDS images keep the operand's own memory order, so staging never transposes:
+//   K-contiguous operand (A transposed / B not): [mn][BK + 8], k fastest.  A
+//     lane's MFMA fragment (8 consecutive k of one row) is one 16-byte read; the
+//     16-byte row padding makes the stride an odd number of 16-byte slots, so the
+//     16 lanes of a ds_read_b128 group hit 16 different slots.
+//   M/N-contiguous operand: [k][BMN + 32], mn fastest.  The fragment is fetched
+//     with two ds_read_b64_tr_b16 (the transposing LDS read of gfx950): each
+//     16-lane group reads a 4 (k) x 16 (mn) block and lane i receives the four
+//     k values of column i.  The 64-byte row padding places the four rows of a
+//     32-lane access on four disjoint quarters of the 64 banks.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,6 +32,7 @@ namespace sbamd {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct HalfTag {};  // IEEE binary16 storage
 struct Bf16Tag {};  // bfloat16 storage
@@ -72,9 +79,9 @@ struct GemmArgs16 {
 // KMAJOR: k contiguous in global memory (A transposed / B not transposed).
 template <int BMN, int BK, int NT, bool KMAJOR>
 struct TileLoader16 {
-  static constexpr int V = 8;        // elements per 16-byte vector
-  static constexpr int S = BK + 8;   // LDS row stride (elements)
-  static constexpr int ELEMS = BMN * S;
+  static constexpr int V = 8;                              // elements per 16-byte vector
+  static constexpr int S = KMAJOR ? (BK + 8) : (BMN + 32);  // LDS row stride (elements)
+  static constexpr int ELEMS = KMAJOR ? BMN * S : BK * S;
   static constexpr int NVEC = BMN * BK / V;
   static_assert(NVEC % NT == 0, "tile must split evenly over the workgroup");
   static constexpr int NV = NVEC / NT;
@@ -121,13 +128,28 @@ struct TileLoader16 {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
-      if (KMAJOR) {
-        *reinterpret_cast<SBAMD_LDS u16x8*>(lds + row * S + col) = reg[i];
-      } else {
-        // the vector runs along mn: transpose on the way in, one element per row
+      *reinterpret_cast<SBAMD_LDS u16x8*>(lds + row * S + col) = reg[i];
+    }
+  }
+
+  // The 8 k-consecutive elements lane `lane` feeds to the MFMA for k-step `s`
+  // (16 k per step) and the 32-row block starting at tile-relative index mn0.
+  __device__ static inline u16x8 fragment(const SBAMD_LDS uint16_t* lds, int s, int mn0, int lane) {
+    const int h = lane >> 5;
+    if (KMAJOR) {
+      return *reinterpret_cast<const SBAMD_LDS u16x8*>(lds + (mn0 + (lane & 31)) * S + 16 * s + 8 * h);
+    } else {
+      const int g = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+      const SBAMD_LDS uint16_t* base = lds + (16 * s + 8 * h + q) * S + mn0 + 16 * g + 4 * p;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SBAMD_LDS s16x4*)base);
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SBAMD_LDS s16x4*)(base + 4 * S));
+      u16x8 out;
 #pragma unroll
-        for (int e = 0; e < V; ++e) lds[(col + e) * S + row] = reg[i][e];
+      for (int e = 0; e < 4; ++e) {
+        out[e] = uint16_t(lo[e]);
+        out[4 + e] = uint16_t(hi[e]);
       }
+      return out;
     }
   }
 };
@@ -140,7 +162,6 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
   static_assert(MI >= 1 && NI >= 1 && BK % 16 == 0, "tile shape");
   using LoadA = TileLoader16<BM, BK, NT, TA>;
   using LoadB = TileLoader16<BN, BK, NT, !TB>;
-  constexpr int SA = LoadA::S, SB = LoadB::S;
   constexpr int A_ELEMS = LoadA::ELEMS, B_ELEMS = LoadB::ELEMS;
   constexpr int STAGE = A_ELEMS + B_ELEMS;
 
@@ -175,7 +196,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
   const bool fast = (m0 + BM <= g.m) && (n0 + BN <= g.n) && g.vec_a && g.vec_b;
   const int nk = int((g.k + BK - 1) / BK);
   const int frag_mn = lane & 31, frag_h = lane >> 5;
-  const int a_row = wm * WTM + frag_mn, b_row = wn * WTN + frag_mn;
+  const int a_row = wm * WTM + frag_mn;
 
   auto load_tile = [&](int kt) {
     const int64_t k0 = int64_t(kt) * BK;
@@ -204,11 +225,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
     for (int s = 0; s < BK / 16; ++s) {
       u16x8 fa[MI], fb[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        fa[i] = *reinterpret_cast<const SBAMD_LDS u16x8*>(as + (a_row + i * 32) * SA + 16 * s + 8 * frag_h);
+      for (int i = 0; i < MI; ++i) fa[i] = LoadA::fragment(as, s, wm * WTM + i * 32, lane);
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        fb[j] = *reinterpret_cast<const SBAMD_LDS u16x8*>(bs + (b_row + j * 32) * SB + 16 * s + 8 * frag_h);
+      for (int j = 0; j < NI; ++j) fb[j] = LoadB::fragment(bs, s, wn * WTN + j * 32, lane);
       // op0 carries the N index, op1 the M index: a lane ends up with one M index
 #pragma unroll
       for (int i = 0; i < MI; ++i)
