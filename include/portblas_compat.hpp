@@ -44,7 +44,8 @@ struct bfloat16_t {
 namespace detail {
 inline void check(int status, sbamd_handle_t h = nullptr) {
   if (status == SBAMD_OK) return;
-  if (status >= SBAMD_INVALID_TRANSA && status <= SBAMD_INVALID_STRIDEB)
+  if ((status >= SBAMD_INVALID_TRANSA && status <= SBAMD_INVALID_STRIDEB) ||
+      (status >= SBAMD_INVALID_UPLO && status <= SBAMD_TRSM_INVALID_DIAG))
     throw std::invalid_argument(sbamd_status_string(status));
   if (status == SBAMD_INVALID_VALUE) throw std::invalid_argument("invalid value");
   std::string msg = sbamd_status_string(status);
@@ -222,6 +223,8 @@ template <>
 struct abi<float, float> {
   using scalar = float;
   static constexpr auto gemm = sbamd_sgemm;
+  static constexpr auto symm = sbamd_ssymm;
+  static constexpr auto trsm = sbamd_strsm;
   static constexpr auto strided = sbamd_sgemm_strided_batched;
   static int batched(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t n, int64_t k, float al, const float* a,
                      int64_t lda, const float* b, int64_t ldb, float be, float* c, int64_t ldc, int64_t batch, int bt) {
@@ -232,6 +235,8 @@ template <>
 struct abi<double, double> {
   using scalar = double;
   static constexpr auto gemm = sbamd_dgemm;
+  static constexpr auto symm = sbamd_dsymm;
+  static constexpr auto trsm = sbamd_dtrsm;
   static constexpr auto strided = sbamd_dgemm_strided_batched;
   static int batched(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t n, int64_t k, double al, const double* a,
                      int64_t lda, const double* b, int64_t ldb, double be, double* c, int64_t ldc, int64_t batch,
@@ -333,6 +338,39 @@ typename sb_handle_t::event_t _gemm_strided_batched(sb_handle_t& sb_handle, char
                              typename api::scalar(_alpha), detail::raw(a_), int64_t(_lda), int64_t(_stridea),
                              detail::raw(b_), int64_t(_ldb), int64_t(_strideb), typename api::scalar(_beta),
                              detail::raw(_C), int64_t(_ldc), int64_t(_stridec), int64_t(batch_size)),
+                sb_handle.native());
+  return sb_handle.record();
+}
+
+// blas::_symm (include/interface/blas3_interface.h:136-145), float and double
+template <typename sb_handle_t, typename container_0_t, typename container_1_t, typename container_2_t,
+          typename element_t, typename index_t>
+typename sb_handle_t::event_t _symm(sb_handle_t& sb_handle, char _side, char _uplo, index_t _M, index_t _N,
+                                    element_t _alpha, container_0_t a_, index_t _lda, container_1_t b_,
+                                    index_t _ldb, element_t _beta, container_2_t _C, index_t _ldc,
+                                    const typename sb_handle_t::event_t& _dependencies = {}) {
+  using out_t = typename detail::elem<container_2_t>::type;
+  using api = detail::abi<out_t, out_t>;
+  sb_handle.depends_on(_dependencies);
+  detail::check(api::symm(sb_handle.native(), _side, _uplo, int64_t(_M), int64_t(_N), out_t(_alpha),
+                          detail::raw(a_), int64_t(_lda), detail::raw(b_), int64_t(_ldb), out_t(_beta),
+                          detail::raw(_C), int64_t(_ldc)),
+                sb_handle.native());
+  return sb_handle.record();
+}
+
+// blas::_trsm (include/interface/blas3_interface.h:125-134), float and double
+template <typename sb_handle_t, typename container_0_t, typename container_1_t, typename element_t,
+          typename index_t>
+typename sb_handle_t::event_t _trsm(sb_handle_t& sb_handle, char side, char uplo, char trans, char diag,
+                                    index_t M, index_t N, element_t alpha, container_0_t A, index_t lda,
+                                    container_1_t B, index_t ldb,
+                                    const typename sb_handle_t::event_t& _dependencies = {}) {
+  using out_t = typename detail::elem<container_1_t>::type;
+  using api = detail::abi<out_t, out_t>;
+  sb_handle.depends_on(_dependencies);
+  detail::check(api::trsm(sb_handle.native(), side, uplo, trans, diag, int64_t(M), int64_t(N), out_t(alpha),
+                          detail::raw(A), int64_t(lda), detail::raw(B), int64_t(ldb)),
                 sb_handle.native());
   return sb_handle.record();
 }

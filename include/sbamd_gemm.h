@@ -44,7 +44,14 @@ enum {
   SBAMD_INVALID_VALUE = 7,   /* negative size, null pointer with work to do */
   SBAMD_HIP_ERROR = 8,       /* a HIP runtime call failed; see last_error */
   SBAMD_ALLOC_FAILED = 9,
-  SBAMD_NOT_SUPPORTED = 10
+  SBAMD_NOT_SUPPORTED = 10,
+  SBAMD_INVALID_UPLO = 11,       /* "invalid _uplo"  symm_interface.hpp:52 */
+  SBAMD_INVALID_SIDE = 12,       /* "invalid _side"  symm_interface.hpp:71 */
+  SBAMD_TRSM_INVALID_SIZE = 13,  /* "invalid matrix size argument" trsm_interface.hpp:115 */
+  SBAMD_TRSM_INVALID_SIDE = 14,  /* "invalid Side argument"        trsm_interface.hpp:124 */
+  SBAMD_TRSM_INVALID_UPLO = 15,  /* "invalid Triangle argument"    trsm_interface.hpp:126 */
+  SBAMD_TRSM_INVALID_TRANS = 16, /* "invalid Transpose argument"   trsm_interface.hpp:128 */
+  SBAMD_TRSM_INVALID_DIAG = 17   /* "invalid Diagonal argument"    trsm_interface.hpp:130 */
 };
 
 /* Batch layouts: include/operations/blas3_trees.h:59 (gemm_batch_type_t). */
@@ -212,6 +219,31 @@ int sbamd_bsgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int
                                  int64_t stride_a, const uint16_t* b, int64_t ldb,
                                  int64_t stride_b, float beta, float* c, int64_t ldc,
                                  int64_t stride_c, int64_t batch);
+
+/* ------------------------------------------------- callers of the GEMM path */
+
+/* Replaces blas::_symm (include/interface/blas3_interface.h:136-145,
+ * src/interface/symm_interface.hpp:34-73).  side 'l': C <- alpha*A*B + beta*C with
+ * A m x m symmetric; side 'r': C <- alpha*B*A + beta*C with A n x n symmetric.
+ * Only the `uplo` ('u' / 'l') triangle of A is read.  Errors: SBAMD_INVALID_UPLO,
+ * then SBAMD_INVALID_SIDE (the reference's order); alpha == 0 scales C as GEMM does. */
+int sbamd_ssymm(sbamd_handle_t h, char side, char uplo, int64_t m, int64_t n, float alpha,
+                const float* a, int64_t lda, const float* b, int64_t ldb, float beta, float* c,
+                int64_t ldc);
+int sbamd_dsymm(sbamd_handle_t h, char side, char uplo, int64_t m, int64_t n, double alpha,
+                const double* a, int64_t lda, const double* b, int64_t ldb, double beta, double* c,
+                int64_t ldc);
+
+/* Replaces blas::_trsm (include/interface/blas3_interface.h:125-134,
+ * src/interface/trsm_interface.hpp:106-396): solves op(A)*X = alpha*B (side 'l') or
+ * X*op(A) = alpha*B (side 'r') for X, which overwrites B (m x n).  A is k x k
+ * triangular (k = m or n), `uplo` says which triangle is stored, diag 'u' assumes a
+ * unit diagonal; the other triangle is never read.  Same algorithm as the reference:
+ * 16x16 diagonal blocks are inverted, then two GEMM calls per block row/column. */
+int sbamd_strsm(sbamd_handle_t h, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
+                float alpha, const float* a, int64_t lda, float* b, int64_t ldb);
+int sbamd_dtrsm(sbamd_handle_t h, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
+                double alpha, const double* a, int64_t lda, double* b, int64_t ldb);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -119,3 +119,39 @@ def compare_vectors(vec, ref, dtype_name=None):
     r = np.ascontiguousarray(ref, dtype=np.float64).ravel()
     assert v.size == r.size
     return load().oracle_compare_f64(v.ctypes.data, r.ctypes.data, v.size, abs_m, rel_m)
+
+
+def _bind_callers(lib):
+    if getattr(lib, "_callers_bound", False):
+        return
+    i64, vp, ch = C.c_int64, C.c_void_p, C.c_char
+    for suf, sc in (("f32", C.c_float), ("f64", C.c_double)):
+        f = getattr(lib, "oracle_symm_" + suf)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, ch, ch, i64, i64, sc, vp, i64, vp, i64, sc, vp, i64]
+        f = getattr(lib, "oracle_trsm_" + suf)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, ch, ch, ch, ch, i64, i64, sc, vp, i64, vp, i64]
+    lib._callers_bound = True
+
+
+def symm(side, uplo, m, n, alpha, a, lda, b, ldb, beta, c, ldc, form=FORM_REF):
+    """_symm of the reference on flat column-major arrays (c updated in place); returns the status code
+    (0 ok, 11 "invalid _uplo", 12 "invalid _side")."""
+    lib = load()
+    _bind_callers(lib)
+    suf, sc = _suffix(c)
+    assert a.dtype == c.dtype and b.dtype == c.dtype
+    return getattr(lib, "oracle_symm_" + suf)(form, _ch(side), _ch(uplo), m, n, sc(alpha), a.ctypes.data, lda,
+                                              b.ctypes.data, ldb, sc(beta), c.ctypes.data, ldc)
+
+
+def trsm(side, uplo, trans, diag, m, n, alpha, a, lda, b, ldb, form=FORM_REF):
+    """_trsm of the reference (16x16 inverted diagonal blocks + GEMM sweeps); b is overwritten with X.
+    Returns the status code (0 ok, 13..17 the reference's invalid_argument cases)."""
+    lib = load()
+    _bind_callers(lib)
+    suf, sc = _suffix(b)
+    assert a.dtype == b.dtype
+    return getattr(lib, "oracle_trsm_" + suf)(form, _ch(side), _ch(uplo), _ch(trans), _ch(diag), m, n, sc(alpha),
+                                              a.ctypes.data, lda, b.ctypes.data, ldb)

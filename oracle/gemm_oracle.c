@@ -261,6 +261,187 @@ enum {
 DEFINE_ORACLE(float, f32, fmaf)
 DEFINE_ORACLE(double, f64, fma)
 
+/* Status codes of the GEMM callers (numerically equal to include/sbamd_gemm.h). */
+enum {
+  ORC_INVALID_UPLO = 11,
+  ORC_INVALID_SIDE = 12,
+  ORC_TRSM_INVALID_SIZE = 13,
+  ORC_TRSM_INVALID_SIDE = 14,
+  ORC_TRSM_INVALID_UPLO = 15,
+  ORC_TRSM_INVALID_TRANS = 16,
+  ORC_TRSM_INVALID_DIAG = 17
+};
+
+static char lower_(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c - 'A' + 'a') : c; }
+
+#define DEFINE_CALLERS(T, SUF, FMA)                                                             \
+  /* _symm: src/interface/symm_interface.hpp:34-73.  One GEMM whose symmetric    */            \
+  /* operand is read through the stored triangle (gemm_local.hpp:813-873); the   */            \
+  /* per-element arithmetic is the GEMM's k-ordered chain over the mirrored      */            \
+  /* matrix, so the mirror is materialised and the GEMM front end called.        */            \
+  int oracle_symm_##SUF(int form, char side, char uplo, int64_t m, int64_t n, T alpha,          \
+                        const T* a, int64_t lda, const T* b, int64_t ldb, T beta, T* c,         \
+                        int64_t ldc) {                                                          \
+    side = lower_(side);                                                                        \
+    uplo = lower_(uplo);                                                                        \
+    if (uplo != 'u' && uplo != 'l') return ORC_INVALID_UPLO; /* :51-53 */                       \
+    if (side != 'l' && side != 'r') return ORC_INVALID_SIDE; /* :70-72 */                       \
+    const int64_t k = side == 'l' ? m : n;                                                      \
+    T* full = (T*)malloc(sizeof(T) * (size_t)(k * k > 0 ? k * k : 1));                          \
+    if (!full) return ORC_ALLOC_FAILED;                                                         \
+    if (!(alpha == (T)0))                                                                       \
+      for (int64_t j = 0; j < k; ++j)                                                           \
+        for (int64_t i = 0; i < k; ++i) {                                                       \
+          const int stored = (uplo == 'u') ? (i <= j) : (i >= j);                               \
+          full[i + j * k] = stored ? a[i + j * lda] : a[j + i * lda];                           \
+        }                                                                                       \
+    int st;                                                                                     \
+    if (side == 'l') /* C <- alpha*A*B + beta*C, :54-59 */                                      \
+      st = oracle_gemm_backend_##SUF(form, 'n', 'n', m, n, k, alpha, full, k, 0, b, ldb, 0,     \
+                                     beta, c, ldc, 0, 1, 0, 1, k > 0 ? k : 1);                  \
+    else /* C <- alpha*B*A + beta*C, :60-69 */                                                  \
+      st = oracle_gemm_backend_##SUF(form, 'n', 'n', m, n, k, alpha, b, ldb, 0, full, k, 0,     \
+                                     beta, c, ldc, 0, 1, 0, 1, k > 0 ? k : 1);                  \
+    free(full);                                                                                 \
+    return st;                                                                                  \
+  }                                                                                             \
+                                                                                                \
+  /* Inverse of one 16x16 diagonal block of a triangular matrix:                 */            \
+  /* src/operations/blas3/trsm.hpp:93-153.  The work-item index i of the         */            \
+  /* reference becomes the inner loop; each barrier-separated phase reads only   */            \
+  /* values written in earlier phases, so running the items in turn is exact.    */            \
+  static void invert_block_##SUF(int unit, int upper, const T* a, int64_t lda, int64_t n,       \
+                                 int64_t origin, T* dst) {                                      \
+    enum { B = 16 };                                                                            \
+    T local[B * B]; /* local[j + i*B] = (row i, column j) */                                    \
+    T sum[B];                                                                                   \
+    for (int i = 0; i < B; ++i)                                                                 \
+      for (int j = 0; j < B; ++j) {                                                             \
+        const int in_range = upper ? (i <= j) && (origin + j < n) : (i >= j) && (origin + i < n); \
+        T v = (T)0;                                                                             \
+        if (in_range) v = (unit && i == j) ? (T)1 : a[(origin + j) * lda + origin + i];         \
+        local[j + i * B] = v;                                                                   \
+      }                                                                                         \
+    if (!unit)                                                                                  \
+      for (int i = 0; i < B; ++i) local[i + i * B] = (T)1 / local[i + i * B];                   \
+    if (upper) {                                                                                \
+      for (int j = 1; j < B; ++j) {                                                             \
+        for (int i = 0; i < j; ++i) {                                                           \
+          T s = (T)0;                                                                           \
+          for (int k = 0; k < j; ++k) s = FMA(local[k + i * B], local[j + k * B], s);           \
+          sum[i] = s;                                                                           \
+        }                                                                                       \
+        for (int i = 0; i < j; ++i) local[j + i * B] = sum[i] * (unit ? (T)-1 : -local[j + j * B]); \
+      }                                                                                         \
+    } else {                                                                                    \
+      for (int j = B - 2; j >= 0; --j) {                                                        \
+        for (int i = j + 1; i < B; ++i) {                                                       \
+          T s = (T)0;                                                                           \
+          for (int k = j + 1; k < B; ++k) s = FMA(local[k + i * B], local[j + k * B], s);       \
+          sum[i] = s;                                                                           \
+        }                                                                                       \
+        for (int i = j + 1; i < B; ++i) local[j + i * B] = sum[i] * (unit ? (T)-1 : -local[j + j * B]); \
+      }                                                                                         \
+    }                                                                                           \
+    for (int j = 0; j < B; ++j)                                                                 \
+      for (int i = 0; i < B; ++i) dst[j * B + i] = local[j + i * B];                            \
+  }                                                                                             \
+                                                                                                \
+  /* _trsm: src/interface/trsm_interface.hpp:106-396, GEMM call for GEMM call.   */            \
+  int oracle_trsm_##SUF(int form, char side, char uplo, char trans, char diag, int64_t M,       \
+                        int64_t N, T alpha, const T* A, int64_t lda, T* B, int64_t ldb) {       \
+    if (M == 0 || N == 0 || lda == 0 || ldb == 0) return ORC_TRSM_INVALID_SIZE; /* :114 */      \
+    side = lower_(side);                                                                        \
+    uplo = lower_(uplo);                                                                        \
+    trans = lower_(trans);                                                                      \
+    diag = lower_(diag);                                                                        \
+    if (side != 'l' && side != 'r') return ORC_TRSM_INVALID_SIDE; /* :123-131 */                \
+    if (uplo != 'u' && uplo != 'l') return ORC_TRSM_INVALID_UPLO;                               \
+    if (trans != 'n' && trans != 't') return ORC_TRSM_INVALID_TRANS;                            \
+    if (diag != 'u' && diag != 'n') return ORC_TRSM_INVALID_DIAG;                               \
+    const int64_t K = side == 'l' ? M : N, bs = 16;                                             \
+    const int unit = diag == 'u', upper = uplo == 'u', left = side == 'l', tr = trans == 't';   \
+    const int64_t nblocks = (K + bs - 1) / bs;                                                  \
+    const int64_t b_elems = ldb * (N - 1) + M; /* :199 */                                       \
+    const int64_t ldx = ldb;                                                                    \
+    T* invA = (T*)calloc((size_t)(nblocks * bs * bs), sizeof(T)); /* :148-155 */                \
+    T* X = (T*)malloc(sizeof(T) * (size_t)b_elems);                                             \
+    if (!invA || !X) {                                                                          \
+      free(invA);                                                                               \
+      free(X);                                                                                  \
+      return ORC_ALLOC_FAILED;                                                                  \
+    }                                                                                           \
+    for (int64_t blk = 0; blk < nblocks; ++blk) /* :165-194 */                                  \
+      invert_block_##SUF(unit, upper, A, lda, K, blk * bs, invA + blk * bs * bs);               \
+    memcpy(X, B, sizeof(T) * (size_t)b_elems); /* :205-208 */                                   \
+    const char tc = tr ? 't' : 'n';                                                             \
+    const T one = (T)1, zero = (T)0, neg = (T)-1;                                               \
+    int st = ORC_OK;                                                                            \
+    /* every call is internal::_gemm: batch 1, strides 0 */                                     \
+    if (left) {                                                                                 \
+      if ((upper && tr) || (!upper && !tr)) { /* :227-251 */                                    \
+        for (int64_t i = 0; i < M && st == ORC_OK; i += bs) {                                   \
+          const int64_t cb = (M - i < bs) ? M - i : bs;                                         \
+          st = oracle_gemm_backend_##SUF(form, tc, 'n', cb, N, cb, i == 0 ? alpha : one,        \
+                                         invA + i * bs, bs, 0, B + i, ldb, 0, zero, X + i, ldx, \
+                                         0, 1, 0, 1, cb);                                       \
+          if (st != ORC_OK || i + bs >= M) break;                                               \
+          const int64_t off = !tr ? ((i + bs) + i * lda) : (i + (bs + i) * lda);                \
+          st = oracle_gemm_backend_##SUF(form, tc, 'n', M - i - bs, N, bs, neg, A + off, lda,   \
+                                         0, X + i, ldx, 0, i == 0 ? alpha : one, B + i + bs,    \
+                                         ldb, 0, 1, 0, 1, bs);                                  \
+        }                                                                                       \
+      } else { /* :267-292 */                                                                   \
+        const int64_t special = (M % bs == 0) ? bs : (M % bs);                                  \
+        const int64_t start = M - special;                                                      \
+        for (int64_t i = start; i >= 0 && st == ORC_OK; i -= bs) {                              \
+          const int64_t cb = (i == start) ? special : bs;                                       \
+          st = oracle_gemm_backend_##SUF(form, tc, 'n', cb, N, cb, i == start ? alpha : one,    \
+                                         invA + i * bs, bs, 0, B + i, ldb, 0, zero, X + i, ldx, \
+                                         0, 1, 0, 1, cb);                                       \
+          if (st != ORC_OK || i - bs < 0) break;                                                \
+          st = oracle_gemm_backend_##SUF(form, tc, 'n', i, N, cb, neg, A + (!tr ? i * lda : i), \
+                                         lda, 0, X + i, ldx, 0, i == start ? alpha : one, B,    \
+                                         ldb, 0, 1, 0, 1, cb);                                  \
+        }                                                                                       \
+      }                                                                                         \
+    } else {                                                                                    \
+      if ((upper && tr) || (!upper && !tr)) { /* :312-337 */                                    \
+        const int64_t special = (N % bs == 0) ? bs : (N % bs);                                  \
+        const int64_t start = N - special;                                                      \
+        for (int64_t i = start; i >= 0 && st == ORC_OK; i -= bs) {                              \
+          const int64_t cb = (i == start) ? special : bs;                                       \
+          st = oracle_gemm_backend_##SUF(form, 'n', tc, M, cb, cb, i == start ? alpha : one,    \
+                                         B + i * ldb, ldb, 0, invA + i * bs, bs, 0, zero,       \
+                                         X + i * ldx, ldx, 0, 1, 0, 1, cb);                     \
+          if (st != ORC_OK || i - bs < 0) break;                                                \
+          st = oracle_gemm_backend_##SUF(form, 'n', tc, M, i, cb, neg, X + i * ldx, ldx, 0,     \
+                                         A + (!tr ? i : i * lda), lda, 0,                       \
+                                         i == start ? alpha : one, B, ldb, 0, 1, 0, 1, cb);     \
+        }                                                                                       \
+      } else { /* :354-380 */                                                                   \
+        for (int64_t i = 0; i < N && st == ORC_OK; i += bs) {                                   \
+          const int64_t cb = (N - i < bs) ? N - i : bs;                                         \
+          st = oracle_gemm_backend_##SUF(form, 'n', tc, M, cb, cb, i == 0 ? alpha : one,        \
+                                         B + i * ldb, ldb, 0, invA + i * bs, bs, 0, zero,       \
+                                         X + i * ldx, ldx, 0, 1, 0, 1, cb);                     \
+          if (st != ORC_OK || i + bs > N) break;                                                \
+          const int64_t off = !tr ? (i + (bs + i) * lda) : ((i + bs) + i * lda);                \
+          st = oracle_gemm_backend_##SUF(form, 'n', tc, M, N - i - bs, bs, neg, X + i * ldx,    \
+                                         ldx, 0, A + off, lda, 0, i == 0 ? alpha : one,         \
+                                         B + (i + bs) * ldb, ldb, 0, 1, 0, 1, bs);              \
+        }                                                                                       \
+      }                                                                                         \
+    }                                                                                           \
+    if (st == ORC_OK) memcpy(B, X, sizeof(T) * (size_t)b_elems); /* :384-389 */                 \
+    free(invA);                                                                                 \
+    free(X);                                                                                    \
+    return st;                                                                                  \
+  }
+
+DEFINE_CALLERS(float, f32, fmaf)
+DEFINE_CALLERS(double, f64, fma)
+
 /* Default strides of _gemm_batched (src/interface/gemm_interface.hpp:213-219). */
 void oracle_default_strides(char transa, char transb, int64_t m, int64_t n, int64_t k, int64_t lda,
                             int64_t ldb, int64_t ldc, int64_t* sa, int64_t* sb, int64_t* sc) {

@@ -7,9 +7,9 @@ include/sbamd_gemm.h).
 """
 from . import _lib
 from .interface import (DeviceBuffer, Event, SB_Handle, SbamdError, _gemm, _gemm_batched,
-                        _gemm_strided_batched, gemm_batch_type_t, helper, uniform_reference)
+                        _gemm_strided_batched, _symm, _trsm, gemm_batch_type_t, helper, uniform_reference)
 
 __all__ = [
     "DeviceBuffer", "Event", "SB_Handle", "SbamdError", "_gemm", "_gemm_batched",
-    "_gemm_strided_batched", "gemm_batch_type_t", "helper", "uniform_reference", "_lib",
+    "_gemm_strided_batched", "_symm", "_trsm", "gemm_batch_type_t", "helper", "uniform_reference", "_lib",
 ]

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsbamd.so")
 OK = 0
 INVALID_TRANSA, INVALID_TRANSB, INVALID_STRIDEC, INVALID_STRIDEA, INVALID_STRIDEB = 1, 2, 3, 4, 5
 INVALID_HANDLE, INVALID_VALUE, HIP_ERROR, ALLOC_FAILED, NOT_SUPPORTED = 6, 7, 8, 9, 10
+INVALID_UPLO, INVALID_SIDE = 11, 12
+TRSM_INVALID_SIZE, TRSM_INVALID_SIDE, TRSM_INVALID_UPLO, TRSM_INVALID_TRANS, TRSM_INVALID_DIAG = 13, 14, 15, 16, 17
 BATCH_STRIDED, BATCH_INTERLEAVED = 0, 1
 KERNEL_AUTO, KERNEL_LARGE, KERNEL_SMALL, KERNEL_SPLITK, KERNEL_NAIVE, KERNEL_HUGE = 0, 1, 2, 3, 4, 5
 KERNEL_INTERLEAVED = 6
@@ -71,6 +73,10 @@ SIGNATURES = {
     "sbamd_hsgemm_strided_batched": (_int, _gemm_strided_sig(_f32)),
     "sbamd_bsgemm_strided_batched": (_int, _gemm_strided_sig(_f32)),
 }
+
+for _p, _sc in (("s", _f32), ("d", _f64)):
+    SIGNATURES[f"sbamd_{_p}symm"] = (_int, [_vp, _ch, _ch, _i64, _i64, _sc, _vp, _i64, _vp, _i64, _sc, _vp, _i64])
+    SIGNATURES[f"sbamd_{_p}trsm"] = (_int, [_vp, _ch, _ch, _ch, _ch, _i64, _i64, _sc, _vp, _i64, _vp, _i64])
 
 _lib = None
 

@@ -8,33 +8,33 @@
 
 #include "sbamd_internal.hpp"
 
-struct sbamd_handle_s {
-  sbamd::Handle impl;
-};
 struct sbamd_event_s {
   hipEvent_t ev;
 };
 
 namespace sbamd {
 
-hipError_t ensure_scratch(Handle* h, size_t bytes) {
+static hipError_t grow(Handle* h, void** buf, size_t* have, size_t bytes) {
   std::lock_guard<std::mutex> lock(h->mu);
-  if (bytes <= h->scratch_bytes) return hipSuccess;
-  if (h->scratch) {
+  if (bytes <= *have) return hipSuccess;
+  if (*buf) {
     // Earlier work on the stream may still read the old buffer.
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return e;
-    e = hipFree(h->scratch);
+    e = hipFree(*buf);
     if (e != hipSuccess) return e;
-    h->scratch = nullptr;
-    h->scratch_bytes = 0;
+    *buf = nullptr;
+    *have = 0;
   }
   const size_t rounded = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-  hipError_t e = hipMalloc(&h->scratch, rounded);
+  hipError_t e = hipMalloc(buf, rounded);
   if (e != hipSuccess) return e;
-  h->scratch_bytes = rounded;
+  *have = rounded;
   return hipSuccess;
 }
+
+hipError_t ensure_scratch(Handle* h, size_t bytes) { return grow(h, &h->scratch, &h->scratch_bytes, bytes); }
+hipError_t ensure_aux(Handle* h, size_t bytes) { return grow(h, &h->aux, &h->aux_bytes, bytes); }
 
 namespace {
 
@@ -247,6 +247,13 @@ const char* sbamd_status_string(int status) {
     case SBAMD_HIP_ERROR: return "HIP runtime error";
     case SBAMD_ALLOC_FAILED: return "device allocation failed";
     case SBAMD_NOT_SUPPORTED: return "not supported";
+    case SBAMD_INVALID_UPLO: return "invalid _uplo";
+    case SBAMD_INVALID_SIDE: return "invalid _side";
+    case SBAMD_TRSM_INVALID_SIZE: return "invalid matrix size argument";
+    case SBAMD_TRSM_INVALID_SIDE: return "invalid Side argument";
+    case SBAMD_TRSM_INVALID_UPLO: return "invalid Triangle argument";
+    case SBAMD_TRSM_INVALID_TRANS: return "invalid Transpose argument";
+    case SBAMD_TRSM_INVALID_DIAG: return "invalid Diagonal argument";
     default: return "unknown status";
   }
 }
@@ -284,6 +291,7 @@ int sbamd_destroy(sbamd_handle_t h) {
   DeviceGuard guard(h->impl.device);
   (void)hipStreamSynchronize(h->impl.stream);
   if (h->impl.scratch) (void)hipFree(h->impl.scratch);
+  if (h->impl.aux) (void)hipFree(h->impl.aux);
   if (h->impl.owns_stream) (void)hipStreamDestroy(h->impl.stream);
   delete h;
   return SBAMD_OK;

@@ -28,9 +28,23 @@ struct Handle {
   // stream is ordered, so consecutive calls may share it.
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // Second scratch area for the GEMM callers: the expanded symmetric matrix of
+  // _symm, the inverted diagonal blocks and the X copy of _trsm.  Kept apart from
+  // the cube because those drivers issue GEMM calls that may use the cube.
+  void* aux = nullptr;
+  size_t aux_bytes = 0;
   std::mutex mu;
   std::string last_error;
 };
+
+}  // namespace sbamd
+
+// The opaque handle of the C ABI is a thin shell around sbamd::Handle.
+struct sbamd_handle_s {
+  sbamd::Handle impl;
+};
+
+namespace sbamd {
 
 // Everything the front end has already validated and normalised.
 template <typename TIn, typename TOut>
@@ -73,7 +87,8 @@ hipError_t run_scale_f64(Handle* h, double* c, int64_t rows, int64_t cols, int64
 hipError_t run_fill_uniform(Handle* h, void* dst, int64_t count, int dtype, uint64_t seed,
                             double lo, double hi);
 
-// Grow the handle's scratch buffer to at least `bytes`.
+// Grow the handle's scratch buffer (split-K cube) / aux buffer to at least `bytes`.
 hipError_t ensure_scratch(Handle* h, size_t bytes);
+hipError_t ensure_aux(Handle* h, size_t bytes);
 
 }  // namespace sbamd

@@ -34,6 +34,13 @@ class SbamdError(RuntimeError):
 
 
 _ARG_ERRORS = {
+    _lib.INVALID_UPLO: "invalid _uplo",
+    _lib.INVALID_SIDE: "invalid _side",
+    _lib.TRSM_INVALID_SIZE: "invalid matrix size argument",
+    _lib.TRSM_INVALID_SIDE: "invalid Side argument",
+    _lib.TRSM_INVALID_UPLO: "invalid Triangle argument",
+    _lib.TRSM_INVALID_TRANS: "invalid Transpose argument",
+    _lib.TRSM_INVALID_DIAG: "invalid Diagonal argument",
     _lib.INVALID_TRANSA: "invalid _TransA",
     _lib.INVALID_TRANSB: "invalid _TransB",
     _lib.INVALID_STRIDEC: "invalid _stridec",
@@ -343,5 +350,33 @@ def _gemm_strided_batched(sb_handle, _TransA, _TransB, _M, _N, _K, _alpha, a_, _
     st = fn(sb_handle._h, _ch(_TransA), _ch(_TransB), int(_M), int(_N), int(_K), scalar(_alpha), a_.ptr,
             int(_lda), int(_stridea), b_.ptr, int(_ldb), int(_strideb), scalar(_beta), _C.ptr,
             int(_ldc), int(_stridec), int(batch_size))
+    _check(sb_handle, st)
+    return [sb_handle.record_event()]
+
+
+_REAL = {"float32": ("s", C.c_float), "float64": ("d", C.c_double)}
+
+
+def _symm(sb_handle, _side, _uplo, _M, _N, _alpha, a_, _lda, b_, _ldb, _beta, _C, _ldc, _dependencies=()):
+    """blas::_symm (include/interface/blas3_interface.h:136-145, src/interface/symm_interface.hpp:34-73)."""
+    if not (a_.dtype == b_.dtype == _C.dtype) or _C.dtype not in _REAL:
+        raise TypeError("_symm exists for float and double")
+    prefix, scalar = _REAL[_C.dtype]
+    sb_handle.depends_on(_dependencies)
+    st = getattr(_lib.load(), f"sbamd_{prefix}symm")(sb_handle._h, _ch(_side), _ch(_uplo), int(_M), int(_N),
+                                                     scalar(_alpha), a_.ptr, int(_lda), b_.ptr, int(_ldb),
+                                                     scalar(_beta), _C.ptr, int(_ldc))
+    _check(sb_handle, st)
+    return [sb_handle.record_event()]
+
+
+def _trsm(sb_handle, side, uplo, trans, diag, M, N, alpha, A, lda, B, ldb, _dependencies=()):
+    """blas::_trsm (include/interface/blas3_interface.h:125-134, src/interface/trsm_interface.hpp:106-396)."""
+    if A.dtype != B.dtype or B.dtype not in _REAL:
+        raise TypeError("_trsm exists for float and double")
+    prefix, scalar = _REAL[B.dtype]
+    sb_handle.depends_on(_dependencies)
+    st = getattr(_lib.load(), f"sbamd_{prefix}trsm")(sb_handle._h, _ch(side), _ch(uplo), _ch(trans), _ch(diag), int(M),
+                                                     int(N), scalar(alpha), A.ptr, int(lda), B.ptr, int(ldb))
     _check(sb_handle, st)
     return [sb_handle.record_event()]
