@@ -1,0 +1,194 @@
+// GEMM kernel-family tuner for libsbamd, with the command line of the reference's
+// auto tuner (tools/auto_tuner/README.md:51-68):
+//
+//   tune_gemm M K N bs rep [batch_type] [--dtype=float|double] [--trans=nn|nt|tn|tt|all]
+//
+// The reference tries every tile configuration compiled into the tuner binary
+// (tools/auto_tuner/gen/*.json) and prints them from worst to best.  Here the
+// candidates are the kernel families of the library -- 256x128 ("huge"), 128x128
+// ("large"), 64x64 ("small"), split-K at several depths, the naive kernel -- each
+// pinned through sbamd_set_kernel, plus what the dispatcher picks by itself
+// ("auto"), so a shape where "auto" is not last in the list is a dispatch-table bug.
+// Every candidate's result is compared with the first candidate's: families other
+// than split-K must agree bit for bit.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sbamd_gemm.h"
+
+namespace {
+
+void check(int st, sbamd_handle_t h, const char* what) {
+  if (st == SBAMD_OK) return;
+  std::string msg = std::string(what) + ": " + sbamd_status_string(st);
+  if (h && st >= SBAMD_HIP_ERROR) msg += std::string(" (") + sbamd_last_error(h) + ")";
+  throw std::runtime_error(msg);
+}
+
+struct Candidate {
+  std::string name;
+  int kernel;
+  int param;
+  bool exact;  // result must match the other exact candidates bit for bit
+};
+
+struct Outcome {
+  Candidate cand;
+  double ms = 0, gflops = 0;
+  bool ok = false, same_bits = true;
+  std::string note;
+};
+
+template <typename T>
+int gemm_call(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t n, int64_t k, const T* a, int64_t lda, const T* b,
+              int64_t ldb, T* c, int64_t ldc, int64_t bs, int batch_type);
+template <>
+int gemm_call<float>(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t n, int64_t k, const float* a, int64_t lda,
+                     const float* b, int64_t ldb, float* c, int64_t ldc, int64_t bs, int batch_type) {
+  return sbamd_sgemm_batched(h, ta, tb, m, n, k, 1.0f, a, lda, b, ldb, 0.0f, c, ldc, bs, batch_type);
+}
+template <>
+int gemm_call<double>(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t n, int64_t k, const double* a, int64_t lda,
+                      const double* b, int64_t ldb, double* c, int64_t ldc, int64_t bs, int batch_type) {
+  return sbamd_dgemm_batched(h, ta, tb, m, n, k, 1.0, a, lda, b, ldb, 0.0, c, ldc, bs, batch_type);
+}
+
+template <typename T>
+void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, int64_t bs, int rep, int batch_type) {
+  const int64_t lda = ta == 'n' ? m : k, ldb = tb == 'n' ? k : n, ldc = m;
+  const int64_t na = m * k * bs, nb = k * n * bs, nc = m * n * bs;
+  void *a = nullptr, *b = nullptr, *c = nullptr;
+  check(sbamd_malloc(h, &a, size_t(na) * sizeof(T)), h, "malloc");
+  check(sbamd_malloc(h, &b, size_t(nb) * sizeof(T)), h, "malloc");
+  check(sbamd_malloc(h, &c, size_t(nc) * sizeof(T)), h, "malloc");
+  const int code = sizeof(T) == 4 ? 0 : 1;
+  check(sbamd_fill_uniform(h, a, na, code, 11, -1.0, 1.0), h, "fill");
+  check(sbamd_fill_uniform(h, b, nb, code, 12, -1.0, 1.0), h, "fill");
+
+  std::vector<Candidate> cands = {{"auto", SBAMD_KERNEL_AUTO, 0, false}};
+  if (batch_type == SBAMD_BATCH_INTERLEAVED && bs > 1) {
+    cands.push_back({"interleaved 4x4 register tile", SBAMD_KERNEL_INTERLEAVED, 0, true});
+  } else {
+    cands.push_back({"huge   256x128 tile, 8 waves", SBAMD_KERNEL_HUGE, 0, true});
+    cands.push_back({"large  128x128 tile, 4 waves", SBAMD_KERNEL_LARGE, 0, true});
+    cands.push_back({"small   64x64  tile, 4 waves", SBAMD_KERNEL_SMALL, 0, true});
+    if (bs == 1)
+      for (int depth : {2, 4, 8, 16, 32, 64, 128}) {
+        if (k / depth < 64) break;
+        cands.push_back({"splitk depth " + std::to_string(depth), SBAMD_KERNEL_SPLITK, depth, false});
+      }
+    if (double(m) * double(n) * double(k) * double(bs) <= 8e9)  // the scalar kernel is for checking, keep it short
+      cands.push_back({"naive  one element per lane", SBAMD_KERNEL_NAIVE, 0, true});
+  }
+
+  std::vector<T> first, got(static_cast<size_t>(nc));
+  std::vector<Outcome> outcomes;
+  const double flops = 2.0 * double(m) * double(n) * double(k) * double(bs);
+  for (const Candidate& cand : cands) {
+    Outcome o;
+    o.cand = cand;
+    try {
+      check(sbamd_set_kernel(h, cand.kernel, cand.param), h, "set_kernel");
+      auto call = [&]() {
+        return gemm_call<T>(h, ta, tb, m, n, k, (const T*)a, lda, (const T*)b, ldb, (T*)c, ldc, bs, batch_type);
+      };
+      check(call(), h, "gemm");  // warm-up and the run whose result is compared
+      check(sbamd_copy_to_host(h, got.data(), c, got.size() * sizeof(T)), h, "copy");
+      check(sbamd_wait(h), h, "wait");
+      if (cand.kernel == SBAMD_KERNEL_AUTO) {
+        int64_t depth = 1, chunk = 0;
+        sbamd_last_splitk(h, &depth, &chunk);
+        static const char* names[] = {"auto", "large", "small", "splitk", "naive", "huge", "interleaved"};
+        const int picked = sbamd_last_kernel(h);
+        o.note = std::string("-> ") + (picked >= 0 && picked <= 6 ? names[picked] : "?");
+        if (depth > 1) o.note += " depth " + std::to_string(depth);
+        o.cand.exact = depth <= 1;
+      }
+      if (o.cand.exact) {
+        if (first.empty()) first = got;
+        else o.same_bits = std::memcmp(first.data(), got.data(), got.size() * sizeof(T)) == 0;
+      }
+      sbamd_event_t e0 = nullptr, e1 = nullptr;
+      check(sbamd_event_record(h, &e0), h, "event");
+      for (int i = 0; i < rep; ++i) check(call(), h, "gemm");
+      check(sbamd_event_record(h, &e1), h, "event");
+      check(sbamd_wait(h), h, "wait");
+      float ms = 0;
+      check(sbamd_event_elapsed_ms(e0, e1, &ms), h, "elapsed");
+      sbamd_event_destroy(e0);
+      sbamd_event_destroy(e1);
+      o.ms = double(ms) / rep;
+      o.gflops = flops / (o.ms * 1e6);
+      o.ok = true;
+    } catch (const std::exception& e) {
+      o.note = e.what();
+    }
+    outcomes.push_back(o);
+  }
+  sbamd_set_kernel(h, SBAMD_KERNEL_AUTO, 0);
+  sbamd_free(h, a), sbamd_free(h, b), sbamd_free(h, c);
+
+  std::stable_sort(outcomes.begin(), outcomes.end(), [](const Outcome& x, const Outcome& y) {
+    if (x.ok != y.ok) return !x.ok;  // failures first, then worst to best
+    return x.gflops < y.gflops;
+  });
+  std::printf("== %s GEMM %c%c  M=%lld K=%lld N=%lld  batch=%lld (%s), %d repetitions\n", sizeof(T) == 4 ? "float" : "double",
+              ta, tb, (long long)m, (long long)k, (long long)n, (long long)bs,
+              batch_type == SBAMD_BATCH_INTERLEAVED ? "interleaved" : "strided", rep);
+  for (const Outcome& o : outcomes) {
+    if (!o.ok) {
+      std::printf("  %-32s  not run: %s\n", o.cand.name.c_str(), o.note.c_str());
+      continue;
+    }
+    std::printf("  %-32s %10.4f ms %12.1f GFLOP/s  %s%s\n", o.cand.name.c_str(), o.ms, o.gflops, o.note.c_str(),
+                o.same_bits ? "" : "  RESULT DIFFERS");
+  }
+  for (const Outcome& o : outcomes)
+    if (o.ok && !o.same_bits) throw std::runtime_error("kernel families disagree on this shape");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::vector<std::string> pos;
+  std::string dtype = "float", trans = "all";
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a.compare(0, 8, "--dtype=") == 0) dtype = a.substr(8);
+    else if (a.compare(0, 8, "--trans=") == 0) trans = a.substr(8);
+    else pos.push_back(a);
+  }
+  if (pos.size() < 5 || pos.size() > 6) {
+    std::fprintf(stderr, "usage: tune_gemm M K N bs rep [strided|interleaved] [--dtype=float|double] [--trans=nn|nt|tn|tt|all]\n");
+    return 2;
+  }
+  try {
+    const int64_t m = std::stoll(pos[0]), k = std::stoll(pos[1]), n = std::stoll(pos[2]), bs = std::stoll(pos[3]);
+    const int rep = std::max(1, std::stoi(pos[4]));
+    int batch_type = SBAMD_BATCH_STRIDED;
+    if (pos.size() == 6) {
+      if (pos[5] == "interleaved") batch_type = SBAMD_BATCH_INTERLEAVED;
+      else if (pos[5] != "strided") throw std::runtime_error("batch_type must be strided or interleaved");
+    }
+    std::vector<std::string> combos = {"nn", "tn", "nt", "tt"};
+    if (trans != "all") combos = {trans};
+    sbamd_handle_t h = nullptr;
+    check(sbamd_create(&h, 0, nullptr), nullptr, "sbamd_create");
+    for (const std::string& t : combos) {
+      if (t.size() != 2) throw std::runtime_error("bad --trans");
+      if (dtype == "double") tune<double>(h, t[0], t[1], m, k, n, bs, rep, batch_type);
+      else tune<float>(h, t[0], t[1], m, k, n, bs, rep, batch_type);
+    }
+    sbamd_destroy(h);
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "tune_gemm: %s\n", e.what());
+    return 1;
+  }
+}
