@@ -1,12 +1,12 @@
 // GEMM kernel-family tuner for libsbamd, with the command line of the reference's
 // auto tuner (tools/auto_tuner/README.md:51-68):
 //
-//   tune_gemm M K N bs rep [batch_type] [--dtype=float|double] [--trans=nn|nt|tn|tt|all]
+//   tune_gemm M K N bs rep [batch_type] [--dtype=float|double] [--trans=nn|nt|tn|tt|all] [--csv=FILE]
 //
 // The reference tries every tile configuration compiled into the tuner binary
 // (tools/auto_tuner/gen/*.json) and prints them from worst to best.  Here the
 // candidates are the kernel families of the library -- 256x128 ("huge"), 128x128
-// ("large"), 64x64 ("small"), split-K at several depths, the naive kernel -- each
+// ("large"), 64x64 ("small"), split-K over each tile at several depths, the naive kernel -- each
 // pinned through sbamd_set_kernel, plus what the dispatcher picks by itself
 // ("auto"), so a shape where "auto" is not last in the list is a dispatch-table bug.
 // Every candidate's result is compared with the first candidate's: families other
@@ -23,6 +23,8 @@
 #include "sbamd_gemm.h"
 
 namespace {
+
+FILE* g_csv = nullptr;  // --csv=FILE: one line per candidate (dtype,ta,tb,m,k,n,bs,kernel,tile,depth,ms)
 
 void check(int st, sbamd_handle_t h, const char* what) {
   if (st == SBAMD_OK) return;
@@ -78,11 +80,19 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     cands.push_back({"huge   256x128 tile, 8 waves", SBAMD_KERNEL_HUGE, 0, true});
     cands.push_back({"large  128x128 tile, 4 waves", SBAMD_KERNEL_LARGE, 0, true});
     cands.push_back({"small   64x64  tile, 4 waves", SBAMD_KERNEL_SMALL, 0, true});
-    if (bs == 1)
-      for (int depth : {2, 4, 8, 16, 32, 64, 128}) {
-        if (k / depth < 64) break;
-        cands.push_back({"splitk depth " + std::to_string(depth), SBAMD_KERNEL_SPLITK, depth, false});
-      }
+    if (bs == 1) {
+      static const char* tile_names[] = {"", "64x64", "128x128", "256x128"};
+      for (int tile = 1; tile <= 3; ++tile)
+        for (int depth : {2, 4, 8, 16, 32, 64, 128}) {
+          if (k / depth < 64) break;
+          // more slabs than it takes to give every compute unit four workgroups only add traffic
+          const int64_t bm = tile == 3 ? 256 : tile == 2 ? 128 : 64, bn = tile == 1 ? 64 : 128;
+          const int64_t tiles = ((m + bm - 1) / bm) * ((n + bn - 1) / bn);
+          if (tiles * depth > 4096 && depth > 2) break;
+          cands.push_back({std::string("splitk ") + tile_names[tile] + " depth " + std::to_string(depth),
+                           SBAMD_KERNEL_SPLITK, depth | (tile << 16), false});
+        }
+    }
     if (double(m) * double(n) * double(k) * double(bs) <= 8e9)  // the scalar kernel is for checking, keep it short
       cands.push_back({"naive  one element per lane", SBAMD_KERNEL_NAIVE, 0, true});
   }
@@ -148,6 +158,10 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     }
     std::printf("  %-32s %10.4f ms %12.1f GFLOP/s  %s%s\n", o.cand.name.c_str(), o.ms, o.gflops, o.note.c_str(),
                 o.same_bits ? "" : "  RESULT DIFFERS");
+    if (g_csv)
+      std::fprintf(g_csv, "%s,%c,%c,%lld,%lld,%lld,%lld,%d,%d,%d,%.6f\n", sizeof(T) == 4 ? "float" : "double", ta, tb,
+                   (long long)m, (long long)k, (long long)n, (long long)bs, o.cand.kernel, (o.cand.param >> 16) & 0xff,
+                   o.cand.param & 0xffff, o.ms);
   }
   for (const Outcome& o : outcomes)
     if (o.ok && !o.same_bits) throw std::runtime_error("kernel families disagree on this shape");
@@ -162,6 +176,7 @@ int main(int argc, char** argv) {
     const std::string a = argv[i];
     if (a.compare(0, 8, "--dtype=") == 0) dtype = a.substr(8);
     else if (a.compare(0, 8, "--trans=") == 0) trans = a.substr(8);
+    else if (a.compare(0, 6, "--csv=") == 0) g_csv = std::fopen(a.substr(6).c_str(), "a");
     else pos.push_back(a);
   }
   if (pos.size() < 5 || pos.size() > 6) {
@@ -186,6 +201,7 @@ int main(int argc, char** argv) {
       else tune<float>(h, t[0], t[1], m, k, n, bs, rep, batch_type);
     }
     sbamd_destroy(h);
+    if (g_csv) std::fclose(g_csv);
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "tune_gemm: %s\n", e.what());

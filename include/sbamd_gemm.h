@@ -96,9 +96,10 @@ int sbamd_get_stream(sbamd_handle_t h, void** out_stream);
 /* Text of the most recent HIP failure seen through this handle. */
 const char* sbamd_last_error(sbamd_handle_t h);
 
-/* Pin a kernel family (SBAMD_KERNEL_*); `param` is family specific
- * (split-K: cube depth, 0 = derive from the compute-unit count as
- * src/operations/blas3/gemm_partial_local.hpp:191-199 does). */
+/* Pin a kernel family (SBAMD_KERNEL_*); `param` is family specific.
+ * Split-K: bits 0-15 = cube depth (0 = derive from the compute-unit count as
+ * src/operations/blas3/gemm_partial_local.hpp:191-199 does), bits 16-23 = tile of
+ * the partial products (0 = automatic, 1 = 64x64, 2 = 128x128, 3 = 256x128). */
 int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param);
 
 /* Which family the last GEMM call on this handle launched (SBAMD_KERNEL_*),

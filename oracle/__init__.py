@@ -128,22 +128,23 @@ def _bind_callers(lib):
     for suf, sc in (("f32", C.c_float), ("f64", C.c_double)):
         f = getattr(lib, "oracle_symm_" + suf)
         f.restype = C.c_int
-        f.argtypes = [C.c_int, ch, ch, i64, i64, sc, vp, i64, vp, i64, sc, vp, i64]
+        f.argtypes = [C.c_int, ch, ch, i64, i64, sc, vp, i64, vp, i64, sc, vp, i64, i64, i64]
         f = getattr(lib, "oracle_trsm_" + suf)
         f.restype = C.c_int
         f.argtypes = [C.c_int, ch, ch, ch, ch, i64, i64, sc, vp, i64, vp, i64]
     lib._callers_bound = True
 
 
-def symm(side, uplo, m, n, alpha, a, lda, b, ldb, beta, c, ldc, form=FORM_REF):
+def symm(side, uplo, m, n, alpha, a, lda, b, ldb, beta, c, ldc, form=FORM_REF, depth=1, k_chunk=0):
     """_symm of the reference on flat column-major arrays (c updated in place); returns the status code
-    (0 ok, 11 "invalid _uplo", 12 "invalid _side")."""
+    (0 ok, 11 "invalid _uplo", 12 "invalid _side").  depth / k_chunk give the K cut of the split-K forms."""
     lib = load()
     _bind_callers(lib)
     suf, sc = _suffix(c)
     assert a.dtype == c.dtype and b.dtype == c.dtype
     return getattr(lib, "oracle_symm_" + suf)(form, _ch(side), _ch(uplo), m, n, sc(alpha), a.ctypes.data, lda,
-                                              b.ctypes.data, ldb, sc(beta), c.ctypes.data, ldc)
+                                              b.ctypes.data, ldb, sc(beta), c.ctypes.data, ldc, depth,
+                                              k_chunk if k_chunk > 0 else max(m if _ch(side).lower() == b"l" else n, 1))
 
 
 def trsm(side, uplo, trans, diag, m, n, alpha, a, lda, b, ldb, form=FORM_REF):

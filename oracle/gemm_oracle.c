@@ -279,9 +279,10 @@ static char lower_(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c - 'A' + 'a
   /* operand is read through the stored triangle (gemm_local.hpp:813-873); the   */            \
   /* per-element arithmetic is the GEMM's k-ordered chain over the mirrored      */            \
   /* matrix, so the mirror is materialised and the GEMM front end called.        */            \
+  /* depth / k_chunk: the K cut for the split-K forms (1 / k otherwise).         */            \
   int oracle_symm_##SUF(int form, char side, char uplo, int64_t m, int64_t n, T alpha,          \
                         const T* a, int64_t lda, const T* b, int64_t ldb, T beta, T* c,         \
-                        int64_t ldc) {                                                          \
+                        int64_t ldc, int64_t depth, int64_t k_chunk) {                          \
     side = lower_(side);                                                                        \
     uplo = lower_(uplo);                                                                        \
     if (uplo != 'u' && uplo != 'l') return ORC_INVALID_UPLO; /* :51-53 */                       \
@@ -298,10 +299,10 @@ static char lower_(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c - 'A' + 'a
     int st;                                                                                     \
     if (side == 'l') /* C <- alpha*A*B + beta*C, :54-59 */                                      \
       st = oracle_gemm_backend_##SUF(form, 'n', 'n', m, n, k, alpha, full, k, 0, b, ldb, 0,     \
-                                     beta, c, ldc, 0, 1, 0, 1, k > 0 ? k : 1);                  \
+                                     beta, c, ldc, 0, 1, 0, depth, k_chunk);                    \
     else /* C <- alpha*B*A + beta*C, :60-69 */                                                  \
       st = oracle_gemm_backend_##SUF(form, 'n', 'n', m, n, k, alpha, b, ldb, 0, full, k, 0,     \
-                                     beta, c, ldc, 0, 1, 0, 1, k > 0 ? k : 1);                  \
+                                     beta, c, ldc, 0, 1, 0, depth, k_chunk);                    \
     free(full);                                                                                 \
     return st;                                                                                  \
   }                                                                                             \

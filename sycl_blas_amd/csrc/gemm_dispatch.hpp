@@ -106,9 +106,97 @@ struct Tiles<double> {
   static constexpr int LARGE_BK = 8, SMALL_BK = 8, HUGE_BK = 16, ONESHOT_BK = 64;
 };
 
-// The reference's tall-skinny predicate (amd_gpu.hpp:77-81).
-inline bool is_tall_skinny(int64_t m, int64_t n, int64_t k, int64_t batch) {
-  return batch == 1 && ((k > 8192 && m <= 1024 && n <= 1024) || (k > 1024 && m <= 256 && n <= 256));
+// What to launch: a tile shape and how many K slabs (1 = a single kernel).
+enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3 };
+struct Plan {
+  int tile;
+  int64_t depth;
+};
+
+// Cost model of one launch, fitted to a sweep of every (tile, depth) pair over
+// M, N in {64..2048}, K in {256..16384} on MI355X (benchmark/tune_gemm --csv).
+// per_k[r-1] = microseconds per unit of K that a compute unit needs for r
+// resident workgroups of the tile (latency-bound at r = 1 for the small tiles,
+// matrix-pipe-bound when the unit is full).
+template <typename T>
+struct CostModel;
+// The constants are a least-squares fit (tools/fit_cost_model.py) to ~1200
+// measured candidates per type; against the best measured candidate of each
+// shape the fitted model's choice is within 3 % at the 90th percentile.
+struct CostOverheads {
+  double t_single;  // one launch, us
+  double t_split;   // partial-product launch + reduction launch, us
+  double bw;        // cube write + read, bytes per us
+  double c_depth;   // reduction: serial walk over the slabs, us per slab
+};
+template <>
+struct CostModel<float> {
+  static constexpr double small_k[4] = {0.0294, 0.0443, 0.0617, 0.0738};
+  static constexpr double large_k[2] = {0.0741, 0.1297};
+  static constexpr double huge_k[1] = {0.1271};
+  static constexpr CostOverheads over = {3.08, 6.88, 4.93e6, 0.0555};
+};
+template <>
+struct CostModel<double> {
+  static constexpr double small_k[4] = {0.0506, 0.0908, 0.1270, 0.1593};
+  static constexpr double large_k[2] = {0.1235, 0.2391};
+  static constexpr double huge_k[1] = {0.2330};
+  static constexpr CostOverheads over = {4.25, 7.29, 5.87e6, 0.0448};
+};
+
+// Estimated microseconds for `tile` with the K range cut into `depth` slabs.
+template <typename T>
+inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t k, int64_t batch, bool ta,
+                          bool tb, int cus) {
+  using C = CostModel<T>;
+  const int bm = tile == TILE_256 ? 256 : tile == TILE_128 ? 128 : 64;
+  const int bn = tile == TILE_64 ? 64 : 128;
+  const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
+  const int occ = tile == TILE_256 ? 1 : tile == TILE_128 ? 2 : 4;
+  const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : C::small_k;
+  const int64_t wgs = ceil_div(m, bm) * ceil_div(n, bn) * batch * depth;
+  const int64_t busiest = ceil_div(wgs, cus);  // workgroups the fullest compute unit runs
+  const int64_t full = busiest / occ, rem = busiest % occ;
+  double us_per_k = double(full) * per_k[occ - 1] + (rem ? per_k[rem - 1] : 0.0);
+  // fp32 with both operands transposed runs the 256x128 tile at 112 instead of 136 TFLOP/s
+  if (tile == TILE_256 && sizeof(T) == 4 && ta && tb) us_per_k *= 1.22;
+  const int64_t k_chunk = bk * ceil_div(k, int64_t(bk) * depth);
+  double us = us_per_k * double(k_chunk);
+  if (depth > 1) {
+    us += C::over.t_split + 2.0 * double(m) * double(n) * double(depth) * sizeof(T) / C::over.bw +
+          C::over.c_depth * double(depth);
+  } else {
+    us += C::over.t_single;
+  }
+  return us;
+}
+
+template <typename T>
+inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, bool ta, bool tb, int cus) {
+  // Short K (the batched 64x64x64 class) has a kernel of its own on the small tile.
+  if (k <= Tiles<T>::ONESHOT_BK && m <= 64 && n <= 64) return {TILE_64, 1};
+  Plan best = {TILE_64, 1};
+  double best_us = 1e300;
+  for (int tile = TILE_64; tile <= TILE_256; ++tile) {
+    const double us = estimate_us<T>(tile, 1, m, n, k, batch, ta, tb, cus);
+    if (us < best_us) best_us = us, best = {tile, 1};
+  }
+  if (batch != 1) return best;
+  // Cutting K (the reference does it for its tall-skinny class only,
+  // amd_gpu.hpp:77-81 / portblas_handle.hpp:296-403) pays whenever M x N alone
+  // cannot fill the chip.  It changes the rounding (partial sums are added slab
+  // by slab), so it has to beat the single launch by a clear margin.
+  static const int depths[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  Plan split = best;
+  double split_us = 1e300;
+  for (int tile = TILE_64; tile <= TILE_256; ++tile)
+    for (int depth : depths) {
+      if (k / depth < 64) break;                                                   // slabs of at least 64
+      if (double(m) * double(n) * depth * sizeof(T) > double(1u << 30)) break;     // cube of at most 1 GiB
+      const double us = estimate_us<T>(tile, depth, m, n, k, 1, ta, tb, cus);
+      if (us < split_us) split_us = us, split = {tile, depth};
+    }
+  return split_us < 0.9 * best_us ? split : best;
 }
 
 template <typename T>
@@ -145,96 +233,71 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
 
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
 
-  int family = h->kernel_override;
-  if (family == SBAMD_KERNEL_AUTO) {
-    if (is_tall_skinny(p.m, p.n, p.k, p.batch)) {
-      family = SBAMD_KERNEL_SPLITK;
-    } else {
-      // The biggest tile that (a) is mostly filled by the matrix and (b) still
-      // gives every compute unit a workgroup; otherwise the 64x64 tile, whose
-      // many small workgroups keep the chip occupied on small and batched shapes
-      // (the role of the reference's low-arithmetic-ratio configurations,
-      // amd_gpu.hpp:242-271).
-      auto fits = [&](int bm, int bn) {
-        const int64_t tm = ceil_div(p.m, bm), tn = ceil_div(p.n, bn);
-        const double fill = double(p.m) * double(p.n) / (double(tm * bm) * double(tn * bn));
-        return fill >= 0.75 && tm * tn * p.batch >= cus;
-      };
-      // (fp32 with both operands transposed measured 112 TFLOP/s on the 256x128
-      // tile against 136 on the 128x128 one at 8192^3, so it skips the big tile.)
-      const bool skip_huge = sizeof(T) == 4 && p.ta && p.tb;
-      if (!skip_huge && fits(256, 128)) family = SBAMD_KERNEL_HUGE;
-      else if (fits(128, 128)) family = SBAMD_KERNEL_LARGE;
-      else family = SBAMD_KERNEL_SMALL;
-    }
+  Plan plan = plan_gemm<T>(p.m, p.n, p.k, p.batch, p.ta, p.tb, cus);
+  // A pinned family overrides the planner (testing / tuning hook).
+  const int pin_depth = h->kernel_param & 0xffff, pin_tile = (h->kernel_param >> 16) & 0xff;
+  switch (h->kernel_override) {
+    case SBAMD_KERNEL_AUTO: break;
+    case SBAMD_KERNEL_LARGE: plan = {TILE_128, 1}; break;
+    case SBAMD_KERNEL_HUGE: plan = {TILE_256, 1}; break;
+    case SBAMD_KERNEL_SMALL: plan = {TILE_64, 1}; break;
+    case SBAMD_KERNEL_NAIVE:
+      h->last_kernel = SBAMD_KERNEL_NAIVE;
+      return launch_naive<T>(g, p.ta, p.tb, h->stream);
+    case SBAMD_KERNEL_SPLITK:
+      if (pin_tile >= TILE_64 && pin_tile <= TILE_256) plan.tile = pin_tile;
+      if (pin_depth > 0) plan.depth = pin_depth;
+      break;
+    default: return hipErrorInvalidValue;
+  }
+  if (p.batch != 1) plan.depth = 1;
+
+  const int bk = plan.tile == TILE_256 ? Tiles<T>::HUGE_BK : plan.tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
+  // K slab of one slice: whole K tiles (gemm_partial_local.hpp:174, :253).
+  int64_t depth = std::max<int64_t>(1, plan.depth);
+  const int64_t k_chunk = std::max<int64_t>(bk, bk * ceil_div(p.k, int64_t(bk) * depth));
+  depth = std::max<int64_t>(1, ceil_div(p.k, k_chunk));
+
+  if (depth > 1) {
+    const int64_t slice = p.m * p.n;
+    hipError_t e = ensure_scratch(h, size_t(slice) * depth * sizeof(T));
+    if (e != hipSuccess) return e;
+    GemmArgs<T> gp = g;
+    gp.c = static_cast<T*>(h->scratch);
+    gp.ldc = p.m;
+    gp.split_k = int32_t(depth);
+    gp.k_chunk = k_chunk;
+    gp.slice_stride = slice;
+    gp.beta_zero = 1;
+    e = plan.tile == TILE_256   ? launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(gp, p.ta, p.tb, h->stream)
+        : plan.tile == TILE_128 ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream)
+                                : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
+    if (e != hipSuccess) return e;
+    const int64_t grid = ceil_div(slice, 256);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)grid), dim3(256), 0, h->stream,
+                       static_cast<const T*>(h->scratch), slice, int(depth), p.c, p.m, p.n, p.ldc, p.beta,
+                       g.beta_zero);
+    h->last_kernel = SBAMD_KERNEL_SPLITK;
+    h->last_depth = depth;
+    h->last_k_chunk = k_chunk;
+    return hipGetLastError();
   }
 
-  if (family == SBAMD_KERNEL_SPLITK) {
-    // Tile for the partial products: the large tile once M and N fill it.
-    const bool big = p.m > 64 && p.n > 64;
-    // 256x128 once M fills it: A is then streamed by half as many tile columns.
-    const bool huge = p.m > 192 && p.n > 64 && !(sizeof(T) == 4 && p.ta && p.tb);
-    const int bm = huge ? 256 : big ? 128 : 64;
-    const int bn = big ? 128 : 64;
-    const int bk = huge ? Tiles<T>::HUGE_BK : big ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
-    const int64_t tiles_mn = ceil_div(p.m, bm) * ceil_div(p.n, bn);
-    // Cube depth: four workgroups per compute unit as in the reference
-    // (src/operations/blas3/gemm_partial_local.hpp:191-199); one per compute unit
-    // for the eight-wave 256x128 workgroups, which measured best at 256x256x4M
-    // (124 TFLOP/s at one per CU, 121 at four) -- unless pinned.
-    const int64_t per_cu = huge ? 1 : 4;
-    int64_t depth = h->kernel_param > 0 ? h->kernel_param : ceil_div(per_cu * int64_t(cus), tiles_mn);
-    // The reference falls back to one final partial kernel for shallow K
-    // (portblas_handle.hpp:323-331).
-    if (h->kernel_param <= 0 && (depth == 1 || p.k <= 2048)) depth = 1;
-    if (p.batch != 1) depth = 1;
-    // K slab of one slice: whole K tiles (gemm_partial_local.hpp:174, :253).
-    const int64_t k_chunk = std::max<int64_t>(bk, bk * ceil_div(p.k, int64_t(bk) * depth));
-    depth = std::max<int64_t>(1, ceil_div(p.k, k_chunk));
-    if (depth > 1) {
-      const int64_t slice = p.m * p.n;
-      hipError_t e = ensure_scratch(h, size_t(slice) * depth * sizeof(T));
-      if (e != hipSuccess) return e;
-      GemmArgs<T> gp = g;
-      gp.c = static_cast<T*>(h->scratch);
-      gp.ldc = p.m;
-      gp.split_k = int32_t(depth);
-      gp.k_chunk = k_chunk;
-      gp.slice_stride = slice;
-      gp.beta_zero = 1;
-      e = huge  ? launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(gp, p.ta, p.tb, h->stream)
-          : big ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream)
-                : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
-      if (e != hipSuccess) return e;
-      const int64_t grid = ceil_div(slice, 256);
-      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)grid), dim3(256), 0, h->stream,
-                         static_cast<const T*>(h->scratch), slice, int(depth), p.c, p.m, p.n,
-                         p.ldc, p.beta, g.beta_zero);
-      h->last_kernel = SBAMD_KERNEL_SPLITK;
-      h->last_depth = depth;
-      h->last_k_chunk = k_chunk;
-      return hipGetLastError();
-    }
-    family = big ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
-  }
-
-  h->last_kernel = family;
-  switch (family) {
-    case SBAMD_KERNEL_LARGE:
+  switch (plan.tile) {
+    case TILE_128:
+      h->last_kernel = SBAMD_KERNEL_LARGE;
       return launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(g, p.ta, p.tb, h->stream);
-    case SBAMD_KERNEL_HUGE:
+    case TILE_256:
+      h->last_kernel = SBAMD_KERNEL_HUGE;
       return launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(g, p.ta, p.tb, h->stream);
-    case SBAMD_KERNEL_SMALL:
+    default:
+      h->last_kernel = SBAMD_KERNEL_SMALL;
       // Short K (the batched 64x64x64 class): stage the whole K range at once --
       // one load burst, one barrier, no K loop -- so a CU overlaps the loads of
       // some items with the matrix work of others.
       if (p.k <= Tiles<T>::ONESHOT_BK && p.k > Tiles<T>::SMALL_BK)
         return launch_tile<T, 64, 64, Tiles<T>::ONESHOT_BK, 2, 2, sizeof(T) == 4 ? 4 : 2>(g, p.ta, p.tb, h->stream);
       return launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(g, p.ta, p.tb, h->stream);
-    case SBAMD_KERNEL_NAIVE:
-      return launch_naive<T>(g, p.ta, p.tb, h->stream);
-    default:
-      return hipErrorInvalidValue;
   }
 }
 

@@ -145,13 +145,28 @@ struct TileLoader {
   // would otherwise steal issue slots from the matrix instructions).
   const T* ptr[NV];
 
-  __device__ inline void init_fast(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t k0, int tid) {
+  //
+  // Tiles that hang over the matrix edge use the same path: a vector whose M/N
+  // index lies past the edge is pointed at the last valid row (K-major) or the
+  // last valid vector (MN-major; the caller guarantees mn_lim % V == 0 there, so
+  // no vector straddles the edge).  What it loads only feeds C elements that are
+  // never stored.
+  __device__ inline void init_fast(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim, int64_t k0,
+                                   int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
-      ptr[i] = KMAJOR ? (x + (k0 + col) + (mn0 + row) * ld) : (x + (mn0 + col) + (k0 + row) * ld);
+      if (KMAJOR) {
+        int64_t mn = mn0 + row;
+        mn = mn < mn_lim ? mn : mn_lim - 1;
+        ptr[i] = x + (k0 + col) + mn * ld;
+      } else {
+        int64_t mn = mn0 + col;
+        mn = mn < mn_lim ? mn : mn_lim - V;
+        ptr[i] = x + mn + (k0 + row) * ld;
+      }
     }
   }
 
@@ -417,8 +432,8 @@ struct GemmBody {
     SBAMD_LDS T* const buf0 = smem;
     SBAMD_LDS T* const buf1 = smem + K::STAGE_ELEMS;
 
-    la.init_fast(a, g.lda, m0, k_begin, tid);
-    lb.init_fast(b, g.ldb, n0, k_begin, tid);
+    la.init_fast(a, g.lda, m0, g.m, k_begin, tid);
+    lb.init_fast(b, g.ldb, n0, g.n, k_begin, tid);
     la.load_fast(g.lda);
     lb.load_fast(g.ldb);
     la.store(buf0, tid);
@@ -548,8 +563,11 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   const int frag_mn = M::lane_mn(lane);
   const int a_mn = wm * K::WTM + frag_mn;
   const int b_mn = wn * K::WTN + frag_mn;
+  // The vector path also serves tiles that hang over the edge, unless a 16-byte
+  // vector along M (N) could straddle it.
   const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
-  if (interior && g.vec_a && g.vec_b && k_end - k_begin >= BK) {
+  const bool clampable = (TA || g.m % M::V == 0) && (!TB || g.n % M::V == 0);
+  if ((interior || clampable) && g.vec_a && g.vec_b && k_end - k_begin >= BK) {
     body.run_pipelined(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
   } else {
     body.run_edge(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
@@ -595,8 +613,19 @@ __global__ void __launch_bounds__(256)
   if (idx >= m * n) return;
   const int64_t row = idx % m;
   const int64_t col = idx / m;
-  T sum = cube[idx];
-  for (int d = 1; d < depth; ++d) sum = sum + cube[idx + int64_t(d) * slice_stride];
+  // Loads go out eight slices at a time (they are independent); the additions
+  // keep the slice order, so the rounding does not depend on the batching.
+  const T* src = cube + idx;
+  T sum = *src;
+  int d = 1;
+  for (; d + 8 <= depth; d += 8) {
+    T v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[int64_t(d + e) * slice_stride];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum = sum + v[e];
+  }
+  for (; d < depth; ++d) sum = sum + src[int64_t(d) * slice_stride];
   T* p = c + row + col * ldc;
   if (!beta_zero) {
     const T bc = beta * (*p);

@@ -72,7 +72,10 @@ def test_config1_1024_cubed(sb_handle):
     sb._gemm(h, "n", "n", n, n, n, 1.5, a_g, n, b_g, n, 0.5, c_g, n)
     got = to_host(h, c_g, np.float32, n * n)
     want = c0.copy()
-    assert oracle.gemm_backend("n", "n", n, n, n, 1.5, a, n, 0, b, n, 0, 0.5, want, n, 0) == 0
+    depth, k_chunk = h.last_splitk()  # replay the K cut if the planner chose one
+    form = oracle.FORM_SPLITK if depth > 1 else oracle.FORM_REF
+    assert oracle.gemm_backend("n", "n", n, n, n, 1.5, a, n, 0, b, n, 0, 0.5, want, n, 0, form=form, depth=depth,
+                               k_chunk=k_chunk) == 0
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
     # the device generator matches its host replay
     assert np.array_equal(a, sb.uniform_reference(n * n, 11).astype(np.float32))

@@ -40,9 +40,11 @@ def test_tall_skinny_grid(sb_handle, name, dtype):
     for case in GRIDS[name]:
         verify_gemm(sb_handle, dtype, *case)
         saw_split |= sb_handle.last_kernel() == _lib.KERNEL_SPLITK
-    # k = 2049 must take the split path; k = 1026 <= 2048 takes one final
-    # partial kernel like the reference (portblas_handle.hpp:323-331).
-    assert saw_split == (name in ("BetaNonZeroLDMatch", "BetaNonZeroLDMultiplied"))
+    # These shapes (a handful of tiles, K in the thousands) must take the split
+    # path.  The reference keeps k <= 2048 in one final partial kernel
+    # (portblas_handle.hpp:323-331); here the planner cuts K whenever M x N alone
+    # cannot fill the chip, and verify_gemm replays the reported cut in the oracle.
+    assert saw_split
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
