@@ -1,6 +1,7 @@
 // 16-bit storage back end: half -> half, half -> float, bfloat16 -> float.
 #include "gemm_dispatch.hpp"
 #include "gemm_half.hpp"
+#include "gemm_half_dma.hpp"
 
 namespace sbamd {
 namespace {
@@ -35,6 +36,32 @@ hipError_t launch16(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream) {
             : launch16_one<Tag, TOut, BM, BN, BK, WM, WN, false, false>(g, stream);
 }
 
+template <typename Tag, typename TOut, bool TA, bool TB>
+hipError_t launch16_dma_one(const GemmArgs16<TOut>& g, hipStream_t stream) {
+  auto kernel = gemm_mfma16_ring_kernel<Tag, TOut, TA, TB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * g.batch;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(DMA_NT), RING_LDS_BYTES, stream, g);
+  return hipGetLastError();
+}
+
+template <typename Tag, typename TOut>
+hipError_t launch16_dma(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream) {
+  g.tiles_m = int32_t(ceil_div(g.m, DMA_BM));
+  g.tiles_n = int32_t(ceil_div(g.n, DMA_BN));
+  if (ta) {
+    return tb ? launch16_dma_one<Tag, TOut, true, true>(g, stream) : launch16_dma_one<Tag, TOut, true, false>(g, stream);
+  }
+  return tb ? launch16_dma_one<Tag, TOut, false, true>(g, stream) : launch16_dma_one<Tag, TOut, false, false>(g, stream);
+}
+
 inline bool vec16_ok(const uint16_t* p, int64_t ld, int64_t stride, int64_t batch) {
   return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 8 == 0) && (batch <= 1 || stride % 8 == 0);
 }
@@ -64,13 +91,22 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
   g.beta_zero = p.beta_zero ? 1 : 0;
 
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
+  // The direct-to-LDS 256x256 kernel needs whole K steps, 16-byte vectors and no
+  // vector straddling the matrix edge.
+  const bool dma_ok = g.vec_a && g.vec_b && p.k >= RING_BK && p.k % RING_BK == 0 && (p.ta || p.m % 8 == 0) &&
+                      (!p.tb || p.n % 8 == 0);
   int family = h->kernel_override;
-  if (family != SBAMD_KERNEL_LARGE && family != SBAMD_KERNEL_SMALL) {
-    const int64_t tm = ceil_div(p.m, 128), tn = ceil_div(p.n, 128);
-    const double fill = double(p.m) * double(p.n) / (double(tm * 128) * double(tn * 128));
-    family = (fill >= 0.75 && tm * tn * p.batch >= cus) ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
+  if (family == SBAMD_KERNEL_HUGE && !dma_ok) family = SBAMD_KERNEL_AUTO;
+  if (family != SBAMD_KERNEL_LARGE && family != SBAMD_KERNEL_SMALL && family != SBAMD_KERNEL_HUGE) {
+    auto fits = [&](int bm, int bn) {
+      const int64_t tm = ceil_div(p.m, bm), tn = ceil_div(p.n, bn);
+      const double fill = double(p.m) * double(p.n) / (double(tm * bm) * double(tn * bn));
+      return fill >= 0.75 && tm * tn * p.batch >= cus;
+    };
+    family = (dma_ok && fits(256, 256)) ? SBAMD_KERNEL_HUGE : fits(128, 128) ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
   }
   h->last_kernel = family;
+  if (family == SBAMD_KERNEL_HUGE) return launch16_dma<Tag, TOut>(g, p.ta, p.tb, h->stream);
   if (family == SBAMD_KERNEL_LARGE) return launch16<Tag, TOut, 128, 128, 64, 2, 2>(g, p.ta, p.tb, h->stream);
   return launch16<Tag, TOut, 64, 64, 32, 2, 2>(g, p.ta, p.tb, h->stream);
 }

@@ -1,0 +1,294 @@
+// 256 x 256 MFMA GEMM for 16-bit storage whose operand tiles go from global memory
+// straight into LDS (global_load_lds_dwordx4, no register staging) through a ring
+// of five LDS stages.
+//
+// Same arithmetic as gemm_mfma16_kernel (gemm_half.hpp): v_mfma_f32_32x32x16, fp32
+// accumulation in k order, one rounding at the end -- the two kernels agree bit for
+// bit.  What changes is the data movement, sized for one 8-wave workgroup per
+// compute unit:
+//   * each wave owns a 128 (M) x 64 (N) block of C: 6 fragment reads feed 8 matrix
+//     instructions per 16 k, a third of the LDS read traffic per flop of the 64 x 64
+//     wave tile (which runs the LDS at its limit);
+//   * a load instruction writes 64 lanes x 16 bytes = 1 KiB of LDS contiguously, so
+//     the LDS image is linear and the bank-conflict-free arrangement is produced by
+//     permuting WHICH 16-byte piece of global memory each lane fetches; fragment
+//     reads apply the same permutation (an involution) to their address.
+// Requirements (checked by the launcher): K a multiple of 32, 16-byte aligned
+// operands with leading dimensions that are multiples of 8, and M (N) a multiple
+// of 8 when it is the contiguous index of A (B).  Tiles that hang over the matrix
+// edge fetch clamped rows/columns, which only feed C elements that are never stored.
+#pragma once
+
+#include <type_traits>
+
+#include "gemm_half.hpp"
+
+namespace sbamd {
+
+constexpr int DMA_BM = 256, DMA_BN = 256, DMA_NT = 512;
+
+typedef __attribute__((address_space(1))) const void* dma_gptr_t;
+typedef __attribute__((address_space(3))) void* dma_lptr_t;
+
+// K steps of 32 through a ring of five LDS stages (all 160 KiB), four tiles in flight.  The loads of tile t + 4 are issued during step t, two pieces
+// behind the matrix instructions of each half step, and are only waited for -- with a
+// counted s_waitcnt, never a full drain -- in the middle of step t + 3, so a load has
+// about three K steps to land.  One raw s_barrier per K step, placed before the
+// matrix instructions of the second half step: by then every wave has finished its
+// fragment reads of tile t (the stage may be refilled right after the barrier) and
+// has seen its own pieces of tile t + 1 land (the first fragments of tile t + 1 are
+// fetched behind the remaining matrix instructions).
+constexpr int RING_BK = 32, RING_STAGES = 5, RING_AHEAD = 4;
+constexpr int RING_OPERAND_BYTES = 256 * RING_BK * 2;       // 16 KiB
+constexpr int RING_STAGE_BYTES = 2 * RING_OPERAND_BYTES;    // 32 KiB
+constexpr int RING_LDS_BYTES = RING_STAGES * RING_STAGE_BYTES;
+
+// Images per stage and operand (16 KiB):
+//   K-contiguous:   [256 mn][32 k], 64-byte rows of four 16-byte pieces; piece c of row
+//                   r sits at position c ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128
+//                   lane group cover the 16 slots of the bank row.
+//   M/N-contiguous: [32 k][256 mn], 512-byte rows of 32 pieces; piece c of row k sits at
+//                   position c ^ ((k & 3) << 2): the four k rows that one
+//                   ds_read_b64_tr_b16 lane group touches land on four different
+//                   64-byte bank segments.
+// ds_read_b64_tr_b16 as inline assembly: behind the builtin the compiler drains every
+// outstanding LDS-writing load (s_waitcnt vmcnt(0)) before each transposing read,
+// which would serialise the ring.  The caller waits (lgkmcnt) before using the result.
+template <int OFF>
+__device__ inline s16x4 ds_read_tr16(uint32_t addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+template <bool KMAJOR>
+struct RingOperand {
+  const uint16_t* src[2];
+
+  __device__ inline void init(const uint16_t* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int L = i * DMA_NT + tid;  // 1024 pieces per operand tile
+      if (KMAJOR) {
+        const int row = L >> 2;
+        const int c = (L & 3) ^ ((row >> 2) & 3);
+        int64_t mn = mn0 + row;
+        mn = mn < mn_lim ? mn : mn_lim - 1;
+        src[i] = x + mn * ld + c * 8;
+      } else {
+        const int krow = L >> 5;
+        const int c = (L & 31) ^ ((krow & 3) << 2);
+        int64_t mn = mn0 + c * 8;
+        mn = mn < mn_lim ? mn : mn_lim - 8;
+        src[i] = x + mn + int64_t(krow) * ld;
+      }
+    }
+  }
+
+  // Piece i of this thread for the tile the pointers address.
+  template <int I>
+  __device__ inline void issue_piece(SBAMD_LDS unsigned char* lds, int wave) {
+    SBAMD_LDS unsigned char* dst = lds + (I * DMA_NT + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((dma_gptr_t)src[I], (dma_lptr_t)dst, 16, 0, 0);
+  }
+  __device__ inline void advance(int64_t ld) {
+    const int64_t step = KMAJOR ? int64_t(RING_BK) : int64_t(RING_BK) * ld;
+    src[0] += step;
+    src[1] += step;
+  }
+
+  // Fragment of k-step S (16 k) for the 32 rows starting at tile-relative mn0.
+  template <int S>
+  __device__ static inline u16x8 fragment(const SBAMD_LDS unsigned char* lds, int mn0, int lane) {
+    const int h = lane >> 5;
+    if (KMAJOR) {
+      const int row = mn0 + (lane & 31);
+      const int c = (2 * S + h) ^ ((row >> 2) & 3);
+      return *reinterpret_cast<const SBAMD_LDS u16x8*>(lds + row * 64 + c * 16);
+    } else {
+      const int g = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+      const int col = mn0 + 16 * g + 4 * p;
+      const int c = (col >> 3) ^ (q << 2);
+      const uint32_t addr = uint32_t(uintptr_t(lds)) + uint32_t((8 * h + q) * 512 + c * 16 + (col & 7) * 2);
+      const s16x4 lo = ds_read_tr16<S * 16 * 512>(addr);
+      const s16x4 hi = ds_read_tr16<S * 16 * 512 + 4 * 512>(addr);
+      u16x8 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        out[e] = uint16_t(lo[e]);
+        out[4 + e] = uint16_t(hi[e]);
+      }
+      return out;
+    }
+  }
+};
+
+template <typename Tag, typename TOut, bool TA, bool TB>
+__global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmArgs16<TOut> g) {
+  constexpr int WM = 2, WN = 4;
+  constexpr int WTM = DMA_BM / WM, WTN = DMA_BN / WN;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  using OpA = RingOperand<TA>;
+  using OpB = RingOperand<!TB>;
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+  SBAMD_LDS unsigned char* smem = (SBAMD_LDS unsigned char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = logical / ntiles;
+  int tm, tn;
+  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
+  const int64_t m0 = int64_t(tm) * DMA_BM, n0 = int64_t(tn) * DMA_BN;
+  const uint16_t* a = g.a + int64_t(z) * g.stride_a;
+  const uint16_t* b = g.b + int64_t(z) * g.stride_b;
+  TOut* c = g.c + int64_t(z) * g.stride_c;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  OpA oa;
+  OpB ob;
+  oa.init(a, g.lda, m0, g.m, tid);
+  ob.init(b, g.ldb, n0, g.n, tid);
+  const int nk = int(g.k / RING_BK);
+
+  auto stage_ptr = [&](int t) { return smem + (t % RING_STAGES) * RING_STAGE_BYTES; };
+
+  // prologue: tiles 0 .. RING_AHEAD-1 (those that exist) go in flight
+#pragma unroll
+  for (int t = 0; t < RING_AHEAD; ++t) {
+    if (t < nk) {
+      SBAMD_LDS unsigned char* st = smem + t * RING_STAGE_BYTES;
+      oa.template issue_piece<0>(st, wave);
+      oa.template issue_piece<1>(st, wave);
+      ob.template issue_piece<0>(st + RING_OPERAND_BYTES, wave);
+      ob.template issue_piece<1>(st + RING_OPERAND_BYTES, wave);
+      oa.advance(g.lda);
+      ob.advance(g.ldb);
+    }
+  }
+  // tile 0 must have landed for every wave before anyone reads it
+  if (nk > RING_AHEAD - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  u16x8 fa[2][MI], fb[2][NI];
+  // Read unit U of a half step: the B fragments first, then the A fragments.
+  auto read_unit = [&](auto unit_tag, auto s_tag, const SBAMD_LDS unsigned char* st, u16x8 (&xa)[MI], u16x8 (&xb)[NI]) {
+    constexpr int U = decltype(unit_tag)::value, S = decltype(s_tag)::value;
+    if constexpr (U < NI) xb[U] = OpB::template fragment<S>(st + RING_OPERAND_BYTES, wn * WTN + U * 32, lane);
+    else xa[U - NI] = OpA::template fragment<S>(st, wm * WTM + (U - NI) * 32, lane);
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+
+  // One half step with its issue order written out: matrix instruction n, then read
+  // unit n of the NEXT half step (six units for eight matrix instructions), a load
+  // piece behind the third and the sixth.  sched_barrier(0) keeps the compiler from
+  // regrouping; the operands of the matrix instructions were waited for before the
+  // last barrier, so nothing in here stalls on memory.
+  auto half_step = [&](auto s_next_tag, auto loads_tag, auto reads_tag, auto piece_tag, const SBAMD_LDS unsigned char* st_next,
+                       SBAMD_LDS unsigned char* fill, u16x8 (&ca)[MI], u16x8 (&cb)[NI], u16x8 (&na)[MI], u16x8 (&nb)[NI]) {
+    constexpr bool LOADS = decltype(loads_tag)::value, READS = decltype(reads_tag)::value;
+    constexpr int PIECE = decltype(piece_tag)::value;
+    auto slot = [&](auto n_tag) {
+      constexpr int N = decltype(n_tag)::value;
+      constexpr int I = N / NI, J = N % NI;
+      acc[I][J] = Mfma16<Tag>::mma(cb[J], ca[I], acc[I][J]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (READS && N < MI + NI) read_unit(std::integral_constant<int, N>{}, s_next_tag, st_next, na, nb);
+      if constexpr (LOADS && N == 2) oa.template issue_piece<PIECE>(fill, wave);
+      if constexpr (LOADS && N == 5) ob.template issue_piece<PIECE>(fill + RING_OPERAND_BYTES, wave);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    slot(std::integral_constant<int, 0>{});
+    slot(std::integral_constant<int, 1>{});
+    slot(std::integral_constant<int, 2>{});
+    slot(std::integral_constant<int, 3>{});
+    slot(std::integral_constant<int, 4>{});
+    slot(std::integral_constant<int, 5>{});
+    slot(std::integral_constant<int, 6>{});
+    slot(std::integral_constant<int, 7>{});
+  };
+  static_assert(MI * NI == 8 && MI + NI <= 8, "the slot list above is written for the 128 x 64 wave tile");
+
+  // first fragments of tile 0
+  {
+    auto all = [&](auto u) { read_unit(u, std::integral_constant<int, 0>{}, smem, fa[0], fb[0]); };
+    all(std::integral_constant<int, 0>{});
+    all(std::integral_constant<int, 1>{});
+    all(std::integral_constant<int, 2>{});
+    all(std::integral_constant<int, 3>{});
+    all(std::integral_constant<int, 4>{});
+    all(std::integral_constant<int, 5>{});
+  }
+
+  // One K step.  LOADS: tile t + RING_AHEAD exists and is issued here; NEXT: tile
+  // t + 1 exists.
+  auto step = [&](int t, auto loads_tag, auto next_tag) {
+    constexpr bool LOADS = decltype(loads_tag)::value;
+    const SBAMD_LDS unsigned char* cur = stage_ptr(t);
+    SBAMD_LDS unsigned char* fill = stage_ptr(t + RING_AHEAD);  // the stage tile t - 1 occupied
+
+    // first half step: matrix work on k 0..15, fragments of k 16..31, piece 0 of A and B
+    half_step(std::integral_constant<int, 1>{}, loads_tag, yes{}, std::integral_constant<int, 0>{}, cur, fill, fa[0], fb[0],
+              fa[1], fb[1]);
+
+    // every fragment read of tile t has returned; own pieces of tile t + 1 have landed
+    if (LOADS) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // second half step: matrix work on k 16..31, first fragments of tile t + 1, piece 1
+    half_step(std::integral_constant<int, 0>{}, loads_tag, next_tag, std::integral_constant<int, 1>{}, stage_ptr(t + 1), fill,
+              fa[1], fb[1], fa[0], fb[0]);
+    if (LOADS) {
+      oa.advance(g.lda);
+      ob.advance(g.ldb);
+    }
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the first fragments
+  __builtin_amdgcn_sched_barrier(0);
+
+  int t = 0;
+  for (; t + RING_AHEAD < nk; ++t) step(t, yes{}, yes{});
+  for (; t + 1 < nk; ++t) step(t, no{}, yes{});
+  if (t < nk) step(t, no{}, no{});
+
+  const bool read_c = !g.beta_zero;
+  const int frag_mn = lane & 31, frag_h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int64_t mm = m0 + wm * WTM + i * 32 + frag_mn;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t nn = n0 + wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_h;
+        if (mm < g.m && nn < g.n) {
+          TOut* p = c + mm + nn * g.ldc;
+          float out = g.alpha * acc[i][j][r];
+          if (read_c) {
+            const float bc = g.beta * load_out(p);
+            out = out + bc;
+          }
+          store_out(p, out);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace sbamd

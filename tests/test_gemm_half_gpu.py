@@ -150,6 +150,30 @@ def test_both_tile_families(sb_handle, pair, family):
         run_case(sb_handle, pair, m, n, k, ta, tb, -2.0, 0.0, ldm=2, offset=8, family=fam)
 
 
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_direct_to_lds_family(sb_handle, pair):
+    # The 256x256 ring kernel (K steps of 32, four tiles in flight): whole tiles, tiles hanging
+    # over both edges, fewer K steps than the ring is deep and many more, padded leading
+    # dimensions and a 16-byte-aligned offset, every transpose combination.
+    fam = _lib.KERNEL_HUGE
+    for (m, n, k), ta, tb in itertools.product([(256, 256, 32), (304, 520, 96), (512, 264, 160), (1000, 776, 256), (264, 256, 1024)],
+                                               "nt", "nt"):
+        run_case(sb_handle, pair, m, n, k, ta, tb, 1.5, 0.5, family=fam)
+        assert sb_handle.last_kernel() == fam
+        run_case(sb_handle, pair, m, n, k, ta, tb, -2.0, 0.0, ldm=2, offset=8, family=fam)
+        assert sb_handle.last_kernel() == fam
+    # shapes it cannot take (K tail, odd M with M contiguous, unaligned offset) fall back to the other tiles
+    run_case(sb_handle, pair, 256, 256, 100, "n", "n", 1.0, 1.0, family=fam)
+    assert sb_handle.last_kernel() != fam
+    run_case(sb_handle, pair, 257, 256, 128, "n", "n", 1.0, 1.0, family=fam)
+    assert sb_handle.last_kernel() != fam
+    run_case(sb_handle, pair, 256, 256, 128, "t", "n", 1.0, 1.0, offset=3, family=fam)
+    assert sb_handle.last_kernel() != fam
+    # ... but an odd M is fine when K is A's contiguous index
+    run_case(sb_handle, pair, 257, 256, 128, "t", "n", 1.0, 1.0, family=fam)
+    assert sb_handle.last_kernel() == fam
+
+
 def test_alpha_zero_and_beta_zero_on_half_output(sb_handle):
     h = sb_handle
     m = n = 16
