@@ -167,7 +167,8 @@ def cpu_baseline(dtype, ta, tb, size, seed):
 
     npdt = NP_DTYPE[dtype]
     m = k = size
-    cols = min(size, 512)
+    # about 10 s of CPU work on 16 cores at 8192^3 (0.1-0.2 TFLOP/s): the first 8192 columns
+    cols = min(size, 8192)
     a = uniform_reference(m * k, seed).astype(npdt)
     lda = k if ta != "n" else m
     if tb == "n":  # B is k x n, a column slab is contiguous
