@@ -90,20 +90,20 @@ hipError_t launch_naive(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stre
   return hipGetLastError();
 }
 
-// Tile families and their K steps, picked by measurement at 8192^3 on MI355X
-// (TFLOP/s NN / NT / TN):
-//   fp32 256x128x32: 136.6 / 134.3 / 137.1    128x128x16: 132.9 / 134.9 / 135.0
-//   fp64 256x128x16:  73.4 /  73.4 /  73.6    128x128x8 :  71.6 /  71.9 /  71.9
-// The small family stages a 64 x 64 x 64 batched item in four steps.
+// Tile families and their K steps, picked by measurement on MI355X: the 256x128 tile
+// at 8192^3 (fp32 BK 32: 138 TFLOP/s, fp64 BK 16: 74), the 128x128 and 64x64 tiles
+// over a sweep of mid-size shapes (doubling their K step from 16 / 8 gained 3 % and
+// 10-15 % there: fewer barriers per matrix instruction for workgroups that run one
+// or two to a compute unit).  K <= 64 on the 64x64 tile is staged in one shot.
 template <typename T>
 struct Tiles;
 template <>
 struct Tiles<float> {
-  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 32, ONESHOT_BK = 64;
+  static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 32, ONESHOT_BK = 64;
 };
 template <>
 struct Tiles<double> {
-  static constexpr int LARGE_BK = 8, SMALL_BK = 8, HUGE_BK = 16, ONESHOT_BK = 64;
+  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64;
 };
 
 // What to launch: a tile shape and how many K slabs (1 = a single kernel).
@@ -131,17 +131,17 @@ struct CostOverheads {
 };
 template <>
 struct CostModel<float> {
-  static constexpr double small_k[4] = {0.0294, 0.0443, 0.0617, 0.0738};
-  static constexpr double large_k[2] = {0.0741, 0.1297};
-  static constexpr double huge_k[1] = {0.1271};
-  static constexpr CostOverheads over = {3.08, 6.88, 4.93e6, 0.0555};
+  static constexpr double small_k[4] = {0.0239, 0.0399, 0.0570, 0.0715};
+  static constexpr double large_k[2] = {0.0709, 0.1300};
+  static constexpr double huge_k[1] = {0.1269};
+  static constexpr CostOverheads over = {3.61, 7.11, 4.85e6, 0.0571};
 };
 template <>
 struct CostModel<double> {
-  static constexpr double small_k[4] = {0.0506, 0.0908, 0.1270, 0.1593};
-  static constexpr double large_k[2] = {0.1235, 0.2391};
-  static constexpr double huge_k[1] = {0.2330};
-  static constexpr CostOverheads over = {4.25, 7.29, 5.87e6, 0.0448};
+  static constexpr double small_k[4] = {0.0460, 0.0804, 0.1138, 0.1415};
+  static constexpr double large_k[2] = {0.1191, 0.2375};
+  static constexpr double huge_k[1] = {0.2323};
+  static constexpr CostOverheads over = {4.75, 8.04, 6.02e6, 0.0295};
 };
 
 // Estimated microseconds for `tile` with the K range cut into `depth` slabs.

@@ -123,7 +123,9 @@ struct RingOperand {
   }
 };
 
-template <typename Tag, typename TOut, bool TA, bool TB>
+// ABLATE is a timing-only diagnostic (bit 1: no loads inside the K loop, bit 2: no matrix
+// instructions, bit 4: no fragment reads); the library instantiates 0.
+template <typename Tag, typename TOut, bool TA, bool TB, int ABLATE = 0>
 __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmArgs16<TOut> g) {
   constexpr int WM = 2, WN = 4;
   constexpr int WTM = DMA_BM / WM, WTN = DMA_BN / WN;
@@ -205,11 +207,11 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
     auto slot = [&](auto n_tag) {
       constexpr int N = decltype(n_tag)::value;
       constexpr int I = N / NI, J = N % NI;
-      acc[I][J] = Mfma16<Tag>::mma(cb[J], ca[I], acc[I][J]);
+      if constexpr (!(ABLATE & 2)) acc[I][J] = Mfma16<Tag>::mma(cb[J], ca[I], acc[I][J]);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (READS && N < MI + NI) read_unit(std::integral_constant<int, N>{}, s_next_tag, st_next, na, nb);
-      if constexpr (LOADS && N == 2) oa.template issue_piece<PIECE>(fill, wave);
-      if constexpr (LOADS && N == 5) ob.template issue_piece<PIECE>(fill + RING_OPERAND_BYTES, wave);
+      if constexpr (READS && N < MI + NI && !(ABLATE & 4)) read_unit(std::integral_constant<int, N>{}, s_next_tag, st_next, na, nb);
+      if constexpr (LOADS && N == 2 && !(ABLATE & 1)) oa.template issue_piece<PIECE>(fill, wave);
+      if constexpr (LOADS && N == 5 && !(ABLATE & 1)) ob.template issue_piece<PIECE>(fill + RING_OPERAND_BYTES, wave);
       __builtin_amdgcn_sched_barrier(0);
     };
     slot(std::integral_constant<int, 0>{});
@@ -236,24 +238,23 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
 
   // One K step.  LOADS: tile t + RING_AHEAD exists and is issued here; NEXT: tile
   // t + 1 exists.
-  auto step = [&](int t, auto loads_tag, auto next_tag) {
+  auto step = [&](const SBAMD_LDS unsigned char* cur, const SBAMD_LDS unsigned char* next, SBAMD_LDS unsigned char* fill,
+                  auto loads_tag, auto next_tag) {
     constexpr bool LOADS = decltype(loads_tag)::value;
-    const SBAMD_LDS unsigned char* cur = stage_ptr(t);
-    SBAMD_LDS unsigned char* fill = stage_ptr(t + RING_AHEAD);  // the stage tile t - 1 occupied
 
     // first half step: matrix work on k 0..15, fragments of k 16..31, piece 0 of A and B
     half_step(std::integral_constant<int, 1>{}, loads_tag, yes{}, std::integral_constant<int, 0>{}, cur, fill, fa[0], fb[0],
               fa[1], fb[1]);
 
     // every fragment read of tile t has returned; own pieces of tile t + 1 have landed
-    if (LOADS) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    if (LOADS && !(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     // second half step: matrix work on k 16..31, first fragments of tile t + 1, piece 1
-    half_step(std::integral_constant<int, 0>{}, loads_tag, next_tag, std::integral_constant<int, 1>{}, stage_ptr(t + 1), fill,
-              fa[1], fb[1], fa[0], fb[0]);
+    half_step(std::integral_constant<int, 0>{}, loads_tag, next_tag, std::integral_constant<int, 1>{}, next, fill, fa[1],
+              fb[1], fa[0], fb[0]);
     if (LOADS) {
       oa.advance(g.lda);
       ob.advance(g.ldb);
@@ -262,10 +263,20 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the first fragments
   __builtin_amdgcn_sched_barrier(0);
 
+  // Steady state: five steps per trip, one per ring stage, so that every LDS address is
+  // the lane's offset plus a compile-time constant.
   int t = 0;
-  for (; t + RING_AHEAD < nk; ++t) step(t, yes{}, yes{});
-  for (; t + 1 < nk; ++t) step(t, no{}, yes{});
-  if (t < nk) step(t, no{}, no{});
+  for (; t + RING_STAGES - 1 + RING_AHEAD < nk; t += RING_STAGES) {
+    step(smem + 0 * RING_STAGE_BYTES, smem + 1 * RING_STAGE_BYTES, smem + 4 * RING_STAGE_BYTES, yes{}, yes{});
+    step(smem + 1 * RING_STAGE_BYTES, smem + 2 * RING_STAGE_BYTES, smem + 0 * RING_STAGE_BYTES, yes{}, yes{});
+    step(smem + 2 * RING_STAGE_BYTES, smem + 3 * RING_STAGE_BYTES, smem + 1 * RING_STAGE_BYTES, yes{}, yes{});
+    step(smem + 3 * RING_STAGE_BYTES, smem + 4 * RING_STAGE_BYTES, smem + 2 * RING_STAGE_BYTES, yes{}, yes{});
+    step(smem + 4 * RING_STAGE_BYTES, smem + 0 * RING_STAGE_BYTES, smem + 3 * RING_STAGE_BYTES, yes{}, yes{});
+  }
+  // the remaining steps (t is a multiple of five here) with the stage computed at run time
+  for (; t + RING_AHEAD < nk; ++t) step(stage_ptr(t), stage_ptr(t + 1), stage_ptr(t + RING_AHEAD), yes{}, yes{});
+  for (; t + 1 < nk; ++t) step(stage_ptr(t), stage_ptr(t + 1), stage_ptr(t + RING_AHEAD), no{}, yes{});
+  if (t < nk) step(stage_ptr(t), stage_ptr(t + 1), stage_ptr(t + RING_AHEAD), no{}, no{});
 
   const bool read_c = !g.beta_zero;
   const int frag_mn = lane & 31, frag_h = lane >> 5;

@@ -20,7 +20,7 @@ KERN_TILE = {2: 1, 1: 2, 5: 3}  # single-launch families -> tile
 
 
 def bk_of(tile, dtype):
-    return {1: 16, 2: 16, 3: 32}[tile] if dtype == "float" else {1: 8, 2: 8, 3: 16}[tile]
+    return {1: 32, 2: 32, 3: 32}[tile] if dtype == "float" else {1: 16, 2: 16, 3: 16}[tile]
 
 
 def features(dtype, tile, depth, m, n, k):
