@@ -61,7 +61,16 @@ __device__ inline s16x4 ds_read_tr16(uint32_t addr) {
   return v;
 }
 
-template <bool KMAJOR>
+template <int SHAPE>
+__device__ inline int ring_swizzle_k(int row) {
+  return (row >> 2) & 3;
+}
+template <int SHAPE>
+__device__ inline int ring_swizzle_mn(int krow) {
+  return (krow & 3) << 2;
+}
+
+template <bool KMAJOR, int SHAPE = 32>
 struct RingOperand {
   const uint16_t* src[2];
 
@@ -71,13 +80,13 @@ struct RingOperand {
       const int L = i * DMA_NT + tid;  // 1024 pieces per operand tile
       if (KMAJOR) {
         const int row = L >> 2;
-        const int c = (L & 3) ^ ((row >> 2) & 3);
+        const int c = (L & 3) ^ ring_swizzle_k<SHAPE>(row);
         int64_t mn = mn0 + row;
         mn = mn < mn_lim ? mn : mn_lim - 1;
         src[i] = x + mn * ld + c * 8;
       } else {
         const int krow = L >> 5;
-        const int c = (L & 31) ^ ((krow & 3) << 2);
+        const int c = (L & 31) ^ ring_swizzle_mn<SHAPE>(krow);
         int64_t mn = mn0 + c * 8;
         mn = mn < mn_lim ? mn : mn_lim - 8;
         src[i] = x + mn + int64_t(krow) * ld;
@@ -121,6 +130,7 @@ struct RingOperand {
       return out;
     }
   }
+
 };
 
 // ABLATE is a timing-only diagnostic (bit 1: no loads inside the K loop, bit 2: no matrix
@@ -242,6 +252,11 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
                   auto loads_tag, auto next_tag) {
     constexpr bool LOADS = decltype(loads_tag)::value;
 
+    // the fragments fetched during the previous half step must have arrived (the
+    // transposing reads are inline assembly: the compiler does not wait for them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
     // first half step: matrix work on k 0..15, fragments of k 16..31, piece 0 of A and B
     half_step(std::integral_constant<int, 1>{}, loads_tag, yes{}, std::integral_constant<int, 0>{}, cur, fill, fa[0], fb[0],
               fa[1], fb[1]);
@@ -301,5 +316,6 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
     }
   }
 }
+
 
 }  // namespace sbamd

@@ -3,7 +3,9 @@
 // against the 128x128 kernel of the library bit for bit.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Isycl_blas_amd/csrc tools/bf16_lab.hip -o tools/bin/bf16_lab
 //   tools/bin/bf16_lab [n=8192] [rounds=5] [trans=nn]
+#include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -113,9 +115,16 @@ int main(int argc, char** argv) {
     v.launch(g);
     CHECK(hipDeviceSynchronize());
     CHECK(hipMemcpy(got.data(), c, count * 4, hipMemcpyDeviceToHost));
-    size_t bad = 0;
-    for (size_t i = 0; i < count; ++i) bad += std::memcmp(&got[i], &want[i], 4) != 0;
-    std::printf("check %-40s %s (%zu of %zu differ)\n", v.name.c_str(), bad ? "MISMATCH" : "ok", bad, count);
+    size_t bad = 0, far = 0;
+    double worst = 0;
+    for (size_t i = 0; i < count; ++i) {
+      bad += std::memcmp(&got[i], &want[i], 4) != 0;
+      const double err = std::fabs(double(got[i]) - double(want[i]));
+      worst = err > worst ? err : worst;
+      far += !(err <= 1e-3 * (1.0 + std::fabs(double(want[i]))));  // also catches NaN
+    }
+    std::printf("check %-40s %s (%zu of %zu differ in bits, %zu beyond 1e-3 relative, max abs diff %.3g)\n", v.name.c_str(),
+                far ? "MISMATCH" : "ok", bad, count, far, worst);
   }
 
   hipEvent_t e0, e1;
