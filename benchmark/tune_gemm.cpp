@@ -5,7 +5,7 @@
 //
 // The reference tries every tile configuration compiled into the tuner binary
 // (tools/auto_tuner/gen/*.json) and prints them from worst to best.  Here the
-// candidates are the kernel families of the library -- 256x128 ("huge"), 128x128
+// candidates are the kernel families of the library -- 256x256 / 256x128 for float / double ("huge"), 128x128
 // ("large"), 64x64 ("small"), split-K over each tile at several depths, the naive kernel -- each
 // pinned through sbamd_set_kernel, plus what the dispatcher picks by itself
 // ("auto"), so a shape where "auto" is not last in the list is a dispatch-table bug.
@@ -77,16 +77,17 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
   if (batch_type == SBAMD_BATCH_INTERLEAVED && bs > 1) {
     cands.push_back({"interleaved 4x4 register tile", SBAMD_KERNEL_INTERLEAVED, 0, true});
   } else {
-    cands.push_back({"huge   256x128 tile, 8 waves", SBAMD_KERNEL_HUGE, 0, true});
+    cands.push_back({sizeof(T) == 4 ? "huge   256x256 tile, 8 waves" : "huge   256x128 tile, 8 waves", SBAMD_KERNEL_HUGE, 0, true});
     cands.push_back({"large  128x128 tile, 4 waves", SBAMD_KERNEL_LARGE, 0, true});
     cands.push_back({"small   64x64  tile, 4 waves", SBAMD_KERNEL_SMALL, 0, true});
     if (bs == 1) {
-      static const char* tile_names[] = {"", "64x64", "128x128", "256x128"};
+      static const char* tile_names[] = {"", "64x64", "128x128", sizeof(T) == 4 ? "256x256" : "256x128"};
       for (int tile = 1; tile <= 3; ++tile)
-        for (int depth : {2, 4, 8, 16, 32, 64, 128}) {
+        for (int depth : {2, 4, 8, 16, 32, 64, 128, 256}) {
           if (k / depth < 64) break;
           // more slabs than it takes to give every compute unit four workgroups only add traffic
-          const int64_t bm = tile == 3 ? 256 : tile == 2 ? 128 : 64, bn = tile == 1 ? 64 : 128;
+          const int64_t bm = tile == 3 ? 256 : tile == 2 ? 128 : 64;
+          const int64_t bn = tile == 1 ? 64 : (tile == 3 && sizeof(T) == 4) ? 256 : 128;
           const int64_t tiles = ((m + bm - 1) / bm) * ((n + bn - 1) / bn);
           if (tiles * depth > 4096 && depth > 2) break;
           cands.push_back({std::string("splitk ") + tile_names[tile] + " depth " + std::to_string(depth),

@@ -90,8 +90,11 @@ hipError_t launch_naive(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stre
   return hipGetLastError();
 }
 
-// Tile families and their K steps, picked by measurement on MI355X: the 256x128 tile
-// at 8192^3 (fp32 BK 32: 138 TFLOP/s, fp64 BK 16: 74), the 128x128 and 64x64 tiles
+// Tile families and their K steps, picked by measurement on MI355X.  The biggest tile
+// at 8192^3: fp32 256x256 (each of the 8 waves owns 64x128; BK 16, the deepest that
+// keeps the main loop free of spills): 143 TFLOP/s against 138 for 256x128x32 -- a
+// third fewer global loads and LDS stores per flop; fp64 256x128 BK 16: 74 (256x256
+// needs 256 accumulator registers per lane).  The 128x128 and 64x64 tiles were tuned
 // over a sweep of mid-size shapes (doubling their K step from 16 / 8 gained 3 % and
 // 10-15 % there: fewer barriers per matrix instruction for workgroups that run one
 // or two to a compute unit).  K <= 64 on the 64x64 tile is staged in one shot.
@@ -99,11 +102,11 @@ template <typename T>
 struct Tiles;
 template <>
 struct Tiles<float> {
-  static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 32, ONESHOT_BK = 64;
+  static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 256, HUGE_OCC = 2;
 };
 template <>
 struct Tiles<double> {
-  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64;
+  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 128, HUGE_OCC = 1;
 };
 
 // What to launch: a tile shape and how many K slabs (1 = a single kernel).
@@ -131,10 +134,10 @@ struct CostOverheads {
 };
 template <>
 struct CostModel<float> {
-  static constexpr double small_k[4] = {0.0239, 0.0399, 0.0570, 0.0715};
-  static constexpr double large_k[2] = {0.0709, 0.1300};
-  static constexpr double huge_k[1] = {0.1269};
-  static constexpr CostOverheads over = {3.61, 7.11, 4.85e6, 0.0571};
+  static constexpr double small_k[4] = {0.0237, 0.0398, 0.0584, 0.0707};
+  static constexpr double large_k[2] = {0.0705, 0.1292};
+  static constexpr double huge_k[1] = {0.2463};  // 256 x 256 tile
+  static constexpr CostOverheads over = {3.53, 7.30, 4.92e6, 0.0498};
 };
 template <>
 struct CostModel<double> {
@@ -150,7 +153,7 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
                           bool tb, int cus) {
   using C = CostModel<T>;
   const int bm = tile == TILE_256 ? 256 : tile == TILE_128 ? 128 : 64;
-  const int bn = tile == TILE_64 ? 64 : 128;
+  const int bn = tile == TILE_64 ? 64 : tile == TILE_128 ? 128 : Tiles<T>::HUGE_BN;
   const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
   const int occ = tile == TILE_256 ? 1 : tile == TILE_128 ? 2 : 4;
   const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : C::small_k;
@@ -158,7 +161,7 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
   const int64_t busiest = ceil_div(wgs, cus);  // workgroups the fullest compute unit runs
   const int64_t full = busiest / occ, rem = busiest % occ;
   double us_per_k = double(full) * per_k[occ - 1] + (rem ? per_k[rem - 1] : 0.0);
-  // fp32 with both operands transposed runs the 256x128 tile at 112 instead of 136 TFLOP/s
+  // fp32 with both operands transposed runs the biggest tile slower than the 128x128 one
   if (tile == TILE_256 && sizeof(T) == 4 && ta && tb) us_per_k *= 1.22;
   const int64_t k_chunk = bk * ceil_div(k, int64_t(bk) * depth);
   double us = us_per_k * double(k_chunk);
@@ -186,7 +189,7 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, bool ta, b
   // amd_gpu.hpp:77-81 / portblas_handle.hpp:296-403) pays whenever M x N alone
   // cannot fill the chip.  It changes the rounding (partial sums are added slab
   // by slab), so it has to beat the single launch by a clear margin.
-  static const int depths[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  static const int depths[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
   Plan split = best;
   double split_us = 1e300;
   for (int tile = TILE_64; tile <= TILE_256; ++tile)
@@ -269,7 +272,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     gp.k_chunk = k_chunk;
     gp.slice_stride = slice;
     gp.beta_zero = 1;
-    e = plan.tile == TILE_256   ? launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(gp, p.ta, p.tb, h->stream)
+    e = plan.tile == TILE_256   ? launch_tile<T, 256, Tiles<T>::HUGE_BN, Tiles<T>::HUGE_BK, 4, 2, Tiles<T>::HUGE_OCC>(gp, p.ta, p.tb, h->stream)
         : plan.tile == TILE_128 ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream)
                                 : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
     if (e != hipSuccess) return e;
@@ -289,7 +292,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       return launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(g, p.ta, p.tb, h->stream);
     case TILE_256:
       h->last_kernel = SBAMD_KERNEL_HUGE;
-      return launch_tile<T, 256, 128, Tiles<T>::HUGE_BK, 4, 2>(g, p.ta, p.tb, h->stream);
+      return launch_tile<T, 256, Tiles<T>::HUGE_BN, Tiles<T>::HUGE_BK, 4, 2, Tiles<T>::HUGE_OCC>(g, p.ta, p.tb, h->stream);
     default:
       h->last_kernel = SBAMD_KERNEL_SMALL;
       // Short K (the batched 64x64x64 class): stage the whole K range at once --
