@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--gather", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="rank logic check on a box with fewer GPUs than ranks: every rank uses GPU 0 and the barrier / "
+                         "max-over-ranks go through gloo; the number it prints is not a multi-GPU measurement")
     return ap.parse_args()
 
 
@@ -219,9 +222,14 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the GEMM path has no CPU fallback")
+    if args.rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import sycl_blas_amd as sb
     from sycl_blas_amd.distributed import block_of, grid_for
@@ -266,7 +274,7 @@ def main():
     kernel_ms = ev0.elapsed_ms(ev1) / args.steps  # device time per launch, events on the kernels' stream
 
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
