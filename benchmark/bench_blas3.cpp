@@ -57,7 +57,7 @@ struct Args {
                "  --csv-param=FILE             parameter rows in the reference's CSV format\n"
                "  --dtype=float|double|half|bf16   (half: half in/out; bf16: bf16 in, float out; gemm ops only)\n"
                "  --device=N                   HIP device ordinal (default 0)\n"
-               "  --kernel=auto|large|small|huge|splitk|naive   pin a GEMM kernel family\n"
+               "  --kernel=auto|large|small|huge|tiny|splitk|naive   pin a GEMM kernel family\n"
                "  --benchmark_format=console|json|csv\n"
                "  --benchmark_out=FILE  --benchmark_out_format=json|csv|console\n"
                "  --benchmark_filter=REGEX     run only rows whose name matches\n"
@@ -299,6 +299,7 @@ const char* kernel_name(int k) {
     case SBAMD_KERNEL_NAIVE: return "naive";
     case SBAMD_KERNEL_HUGE: return "huge";
     case SBAMD_KERNEL_INTERLEAVED: return "interleaved";
+    case SBAMD_KERNEL_TINY: return "tiny";
     default: return "-";
   }
 }
@@ -310,6 +311,7 @@ int kernel_code(const std::string& s) {
   if (s == "huge") return SBAMD_KERNEL_HUGE;
   if (s == "splitk") return SBAMD_KERNEL_SPLITK;
   if (s == "naive") return SBAMD_KERNEL_NAIVE;
+  if (s == "tiny") return SBAMD_KERNEL_TINY;
   throw std::runtime_error("unknown --kernel " + s);
 }
 

@@ -66,8 +66,9 @@ enum {
   SBAMD_KERNEL_SMALL = 2,    /* 64x64 macro tile (batched / small shapes)  */
   SBAMD_KERNEL_SPLITK = 3,   /* tall-skinny: K slabs -> cube -> reduction  */
   SBAMD_KERNEL_NAIVE = 4,    /* one thread per C element, sequential k     */
-  SBAMD_KERNEL_HUGE = 5,     /* 256x128 macro tile                         */
-  SBAMD_KERNEL_INTERLEAVED = 6 /* batch-contiguous layout; reported, not pinnable */
+  SBAMD_KERNEL_HUGE = 5,     /* 256x256 (float) / 256x128 (double) macro tile */
+  SBAMD_KERNEL_INTERLEAVED = 6, /* batch-contiguous layout; reported, not pinnable */
+  SBAMD_KERNEL_TINY = 7      /* 32x32 macro tile, one wavefront (batches of small matrices) */
 };
 
 typedef struct sbamd_handle_s* sbamd_handle_t;
@@ -99,7 +100,7 @@ const char* sbamd_last_error(sbamd_handle_t h);
 /* Pin a kernel family (SBAMD_KERNEL_*); `param` is family specific.
  * Split-K: bits 0-15 = cube depth (0 = derive from the compute-unit count as
  * src/operations/blas3/gemm_partial_local.hpp:191-199 does), bits 16-23 = tile of
- * the partial products (0 = automatic, 1 = 64x64, 2 = 128x128, 3 = 256x128). */
+ * the partial products (0 = automatic, 1 = 64x64, 2 = 128x128, 3 = the biggest tile). */
 int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param);
 
 /* Which family the last GEMM call on this handle launched (SBAMD_KERNEL_*),

@@ -102,15 +102,15 @@ template <typename T>
 struct Tiles;
 template <>
 struct Tiles<float> {
-  static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 256, HUGE_OCC = 2;
+  static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 256, HUGE_OCC = 2, TINY_BK = 16;
 };
 template <>
 struct Tiles<double> {
-  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 128, HUGE_OCC = 1;
+  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 128, HUGE_OCC = 1, TINY_BK = 8;
 };
 
 // What to launch: a tile shape and how many K slabs (1 = a single kernel).
-enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3 };
+enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5 };
 struct Plan {
   int tile;
   int64_t depth;
@@ -176,6 +176,12 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
 
 template <typename T>
 inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, bool ta, bool tb, int cus) {
+  // Batches of tiny matrices (the shapes the reference's interleaved layout exists
+  // for): a 64x64 tile would be mostly padding.  Up to 16x16 one lane per C element
+  // wins (4^3 x 65536: 5.6 us against 244; 16^3 x 8192: 14 against 36), up to 32x32 a
+  // one-wave 32x32 tile.  All of them run the same k-ordered chain per element.
+  if (batch > 1 && m <= 16 && n <= 16) return {TILE_NAIVE, 1};
+  if (batch > 1 && m <= 32 && n <= 32) return {TILE_32, 1};
   // Short K (the batched 64x64x64 class) has a kernel of its own on the small tile.
   if (k <= Tiles<T>::ONESHOT_BK && m <= 64 && n <= 64) return {TILE_64, 1};
   Plan best = {TILE_64, 1};
@@ -244,16 +250,24 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     case SBAMD_KERNEL_LARGE: plan = {TILE_128, 1}; break;
     case SBAMD_KERNEL_HUGE: plan = {TILE_256, 1}; break;
     case SBAMD_KERNEL_SMALL: plan = {TILE_64, 1}; break;
-    case SBAMD_KERNEL_NAIVE:
-      h->last_kernel = SBAMD_KERNEL_NAIVE;
-      return launch_naive<T>(g, p.ta, p.tb, h->stream);
+    case SBAMD_KERNEL_TINY: plan = {TILE_32, 1}; break;
+    case SBAMD_KERNEL_NAIVE: plan = {TILE_NAIVE, 1}; break;
     case SBAMD_KERNEL_SPLITK:
       if (pin_tile >= TILE_64 && pin_tile <= TILE_256) plan.tile = pin_tile;
+      else if (plan.tile > TILE_256) plan.tile = TILE_64;
       if (pin_depth > 0) plan.depth = pin_depth;
       break;
     default: return hipErrorInvalidValue;
   }
-  if (p.batch != 1) plan.depth = 1;
+  if (p.batch != 1 || plan.tile > TILE_256) plan.depth = 1;
+  if (plan.tile == TILE_NAIVE) {
+    h->last_kernel = SBAMD_KERNEL_NAIVE;
+    return launch_naive<T>(g, p.ta, p.tb, h->stream);
+  }
+  if (plan.tile == TILE_32) {
+    h->last_kernel = SBAMD_KERNEL_TINY;
+    return launch_tile<T, 32, 32, Tiles<T>::TINY_BK, 1, 1, 4>(g, p.ta, p.tb, h->stream);
+  }
 
   const int bk = plan.tile == TILE_256 ? Tiles<T>::HUGE_BK : plan.tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
   // K slab of one slice: whole K tiles (gemm_partial_local.hpp:174, :253).

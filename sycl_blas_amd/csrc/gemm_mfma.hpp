@@ -691,17 +691,33 @@ __global__ void __launch_bounds__(256) gemm_interleaved_kernel(const GemmArgs<T>
 #pragma unroll
     for (int j = 0; j < IC; ++j) acc[i][j] = T(0);
 
+  // Row / column pointers are set up once (clamped rows and columns feed unstored
+  // elements only) and advanced by a uniform stride per k.
+  const T* pa[IR];
+  const T* pb[IC];
+#pragma unroll
+  for (int i = 0; i < IR; ++i) {
+    const int64_t r = r0 + i < g.m ? r0 + i : g.m - 1;
+    pa[i] = g.a + (TA ? r * g.lda : r) * nb + b;
+  }
+#pragma unroll
+  for (int j = 0; j < IC; ++j) {
+    const int64_t c = c0 + j < g.n ? c0 + j : g.n - 1;
+    pb[j] = g.b + (TB ? c : c * g.ldb) * nb + b;
+  }
+  const int64_t step_a = (TA ? int64_t(1) : g.lda) * nb;
+  const int64_t step_b = (TB ? g.ldb : int64_t(1)) * nb;
   for (int64_t k = 0; k < g.k; ++k) {
     T av[IR], bv[IC];
 #pragma unroll
     for (int i = 0; i < IR; ++i) {
-      const int64_t r = r0 + i < g.m ? r0 + i : g.m - 1;  // clamped rows feed unstored elements only
-      av[i] = g.a[(TA ? (k + r * g.lda) : (r + k * g.lda)) * nb + b];
+      av[i] = *pa[i];
+      pa[i] += step_a;
     }
 #pragma unroll
     for (int j = 0; j < IC; ++j) {
-      const int64_t c = c0 + j < g.n ? c0 + j : g.n - 1;
-      bv[j] = g.b[(TB ? (c + k * g.ldb) : (k + c * g.ldb)) * nb + b];
+      bv[j] = *pb[j];
+      pb[j] += step_b;
     }
 #pragma unroll
     for (int i = 0; i < IR; ++i)

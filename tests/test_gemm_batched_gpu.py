@@ -62,7 +62,7 @@ def test_gemm_strided_batched_grid(sb_handle, name, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
-@pytest.mark.parametrize("family", ["LARGE", "SMALL", "HUGE", "NAIVE"])
+@pytest.mark.parametrize("family", ["LARGE", "SMALL", "HUGE", "NAIVE", "TINY"])
 def test_batched_every_kernel_family(sb_handle, family, dtype):
     sb_handle.set_kernel(getattr(_lib, "KERNEL_" + family))
     try:
@@ -77,3 +77,17 @@ def test_config3_shape_sample(sb_handle):
     # BASELINE config #3 at reduced batch: strided-batched SGEMM of 64x64x64 items.
     verify_gemm_strided(sb_handle, np.float32, 0, 64, 64, 64, 64, "n", "n", 1.0, 0.0, 1, 1, 1, 1, 1, 1)
     assert sb_handle.last_kernel() == _lib.KERNEL_SMALL
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_batches_of_tiny_matrices(sb_handle, dtype):
+    # Shapes the 64x64 tile would mostly pad: up to 16x16 takes one lane per C element, up to
+    # 32x32 the one-wave 32x32 tile; both keep the k-ordered chain (bitwise against the oracle).
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    for (m, n, k, batch), want in [((4, 4, 4, 300), _lib.KERNEL_NAIVE), ((8, 8, 8, 64), _lib.KERNEL_NAIVE),
+                                   ((16, 9, 40, 17), _lib.KERNEL_NAIVE), ((17, 16, 16, 33), _lib.KERNEL_TINY),
+                                   ((24, 24, 24, 50), _lib.KERNEL_TINY), ((32, 32, 100, 9), _lib.KERNEL_TINY),
+                                   ((33, 32, 32, 9), _lib.KERNEL_SMALL)]:
+        for ta, tb in itertools.product("nt", "nt"):
+            verify_gemm_strided(sb_handle, dtype, 3, batch, m, n, k, ta, tb, 1.5, 0.5, 2, 1, 1, 1, 1, 2)
+            assert sb_handle.last_kernel() == want

@@ -52,7 +52,7 @@ FAMILY_SHAPES = [(1, 1, 1), (7, 9, 5), (33, 65, 31), (64, 64, 64), (129, 127, 70
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
-@pytest.mark.parametrize("family", ["LARGE", "SMALL", "HUGE", "NAIVE"])
+@pytest.mark.parametrize("family", ["LARGE", "SMALL", "HUGE", "NAIVE", "TINY"])
 def test_every_kernel_family(sb_handle, family, dtype):
     sb_handle.set_kernel(getattr(_lib, "KERNEL_" + family))
     try:
