@@ -130,3 +130,54 @@ def test_config4_full_k(sb_handle):
     assert oracle.compare_vectors(got[:m * cols], plain) == -1
     for buf in (a_g, b_g, c_g):
         helper.deallocate(buf)
+
+
+@pytest.mark.parametrize("ta", ["n", "t"])
+def test_operand_beyond_2_to_31_elements(sb_handle, ta):
+    # A holds 49152 x 49152 = 2.4e9 floats (9.7 GB): element offsets inside the kernels exceed 32 bits
+    # (the reference's default index type overflows here).  Sampled C elements are recomputed
+    # from single rows of A and columns of B replayed on the host, bit for bit.
+    h = sb_handle
+    h.set_kernel(_lib.KERNEL_AUTO)
+    m = k = 49152
+    n = 512
+    a_g = device_operand(h, np.float32, m * k, 301)
+    b_g = device_operand(h, np.float32, k * n, 302)
+    c_g = helper.allocate(h, np.float32, m * n)
+    try:
+        sb._gemm(h, ta, "n", m, n, k, 1.0, a_g, m if ta == "n" else k, b_g, k, 0.0, c_g, m)
+        h.wait()
+        depth, k_chunk = h.last_splitk()
+        c = to_host(h, c_g, np.float32, m * n)
+        assert np.isfinite(c).all()
+        rng = np.random.default_rng(9)
+        rows = np.concatenate([[0, m - 1, 43691, 43690], rng.integers(0, m, 20)])
+        cols = np.concatenate([[0, n - 1, 255, 256], rng.integers(0, n, 20)])
+        kk = np.arange(k, dtype=np.uint64)
+        for i, j in zip(rows, cols):
+            # element (i, l) of op(A): 'n' -> i + l*m, 't' -> l + i*k
+            idx = (np.uint64(i) + kk * np.uint64(m)) if ta == "n" else (kk + np.uint64(i) * np.uint64(k))
+            a_row = _replay(idx, 301).astype(np.float32)
+            b_col = sb.uniform_reference(k, 302, start=int(j) * k).astype(np.float32)
+            want = np.zeros(1, dtype=np.float32)
+            form = oracle.FORM_SPLITK if depth > 1 else oracle.FORM_REF
+            # a 1 x 1 product: op(A) as a row vector (lda = 1), B as a column
+            assert oracle.gemm_backend("n", "n", 1, 1, k, 1.0, a_row, 1, 0, b_col, k, 0, 0.0, want, 1, 0, form=form,
+                                       depth=depth, k_chunk=k_chunk) == 0
+            got = c[int(i) + int(j) * m]
+            assert got.tobytes() == want[0].tobytes(), f"C[{i},{j}] = {got!r}, expected {want[0]!r}"
+    finally:
+        for buf in (a_g, b_g, c_g):
+            helper.deallocate(buf)
+
+
+def _replay(indices, seed, lo=-2.0, hi=5.0):
+    """sbamd_fill_uniform's value at arbitrary element indices (uint64 array), as float64."""
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) * np.uint64(0xD1342543DE82EF95) + indices
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    u = (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return lo + (hi - lo) * u
