@@ -91,3 +91,19 @@ def test_batches_of_tiny_matrices(sb_handle, dtype):
         for ta, tb in itertools.product("nt", "nt"):
             verify_gemm_strided(sb_handle, dtype, 3, batch, m, n, k, ta, tb, 1.5, 0.5, 2, 1, 1, 1, 1, 2)
             assert sb_handle.last_kernel() == want
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_interleaved_items_big_enough_to_repack(sb_handle, dtype):
+    # Interleaved items with enough arithmetic per byte (about 128^3 and more) are repacked into per-item matrices and run on the
+    # strided kernels; the result lands back in the interleaved buffer, padding rows untouched
+    # (verify_gemm compares the whole buffer with the oracle bit for bit).
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    for (m, n, k, batch), (ta, tb) in itertools.product([(160, 128, 192, 5), (130, 257, 200, 3), (192, 192, 192, 9)],
+                                                        itertools.product("nt", "nt")):
+        verify_gemm(sb_handle, dtype, 0, batch, m, n, k, ta, tb, 1.5, 0.5, 2, 3, 2, batch_type=interleaved)
+        assert sb_handle.last_kernel() != _lib.KERNEL_INTERLEAVED
+        verify_gemm(sb_handle, dtype, 7, batch, m, n, k, ta, tb, -1.0, 0.0, 1, 1, 1, batch_type=interleaved)
+    # just below the threshold the lanes-over-batch kernel still runs
+    verify_gemm(sb_handle, dtype, 0, 4, 31, 200, 200, "n", "n", 1.0, 1.0, 1, 1, 1, batch_type=interleaved)
+    assert sb_handle.last_kernel() == _lib.KERNEL_INTERLEAVED
