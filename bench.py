@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Dense MFMA peaks of one MI355X (TFLOP/s) and its HBM3E peak (GB/s).
-PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}  # dense MFMA peaks, TFLOP/s
 PEAK_HBM_GBS = 8000.0
 NP_DTYPE = {"f32": np.float32, "f64": np.float64}
 GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
@@ -112,6 +112,12 @@ def side_measurements(torch, sb, handle, size):
                                        "pct_mfma_peak": round(100 * tf / PEAK_TFLOPS[dt], 2)}
         del o
 
+    # config #1: the sample's call, SGEMM 1024^3 NN (the reference's CPU-runnable case)
+    o = Operands(torch, sb, handle, "f32", "n", "n", 1024, 1024, 1024, 778)
+    ms = device_time_ms(sb, handle, lambda: o.run(sb, handle), 50, warm=10)
+    extras["sgemm_1024_nn"] = {"us": round(ms * 1e3, 2), "tflops": round(2.0 * 1024 ** 3 / ms / 1e9, 2)}
+    del o
+
     # config #3: batch 4096 of 64x64x64, strides 4096 elements, beta = 0
     bm, batch = 64, 4096
     per = bm * bm
@@ -156,7 +162,9 @@ def side_measurements(torch, sb, handle, size):
     for tr in ("tn", "nn"):
         ms = device_time_ms(sb, handle, lambda: sb._gemm(handle, tr[0], tr[1], size, size, size, 1.0, a, size, b, size,
                                                           0.0, c, size), 3, warm=1)
-        extras[f"bf16_f32out_{tr}_{size}"] = {"ms": round(ms, 4), "tflops": round(2.0 * size ** 3 / ms / 1e9, 1)}
+        tf = 2.0 * size ** 3 / ms / 1e9
+        extras[f"bf16_f32out_{tr}_{size}"] = {"ms": round(ms, 4), "tflops": round(tf, 1),
+                                              "pct_mfma_peak": round(100 * tf / PEAK_TFLOPS["bf16"], 2)}
     for buf in (a, b, c):
         helper.deallocate(buf)
     return extras
@@ -188,7 +196,22 @@ def cpu_baseline(dtype, ta, tb, size, seed):
     dt = time.perf_counter() - t0
     assert st == 0
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    # the reference's own ground-truth library (system CBLAS) on the same host cores, for scale
+    openblas = None
+    try:
+        from scipy.linalg import blas
+        fn = blas.sgemm if npdt == np.float32 else blas.dgemm
+        sz = 4096
+        x = np.asfortranarray(a[: sz * sz].reshape(sz, sz))
+        y = np.asfortranarray(b[: sz * sz].reshape(sz, sz))
+        fn(1.0, x, y)
+        t1 = time.perf_counter()
+        fn(1.0, x, y)
+        openblas = round(2.0 * sz ** 3 / (time.perf_counter() - t1) / 1e12, 4)
+    except Exception:
+        pass
     return {
+        "openblas_tflops_4096": openblas,
         "value": round(2.0 * m * cols * k / dt / 1e12, 5),
         "unit": "TFLOP/s",
         "cores": threads,
