@@ -18,7 +18,7 @@ hipError_t launch16_one(const GemmArgs16<TOut>& g, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * g.batch;
+  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * (g.split_k > 1 ? g.split_k : g.batch);
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds, stream, g);
   return hipGetLastError();
@@ -89,6 +89,9 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
   g.alpha = alpha;
   g.beta = beta;
   g.beta_zero = p.beta_zero ? 1 : 0;
+  g.split_k = 1;
+  g.k_chunk = p.k;
+  g.slice_stride = 0;
 
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
   // The direct-to-LDS 256x256 kernel needs whole K steps, 16-byte vectors and no
@@ -104,6 +107,45 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
       return fill >= 0.75 && tm * tn * p.batch >= cus;
     };
     family = (dma_ok && fits(256, 256)) ? SBAMD_KERNEL_HUGE : fits(128, 128) ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
+  }
+  // Few 64x64 tiles and a long K (thin transformer shapes: 48 x 4096 x 4096, 224 x 1024 x 32768):
+  // cut K over extra workgroups of the 64x64 kernel, fp32 partial sums in the handle's
+  // cube, one reduction that also applies beta*C and rounds to the output type.
+  if (h->kernel_override == SBAMD_KERNEL_AUTO || h->kernel_override == SBAMD_KERNEL_SPLITK) {
+    const int64_t tiles64 = ceil_div(p.m, 64) * ceil_div(p.n, 64);
+    int64_t depth = h->kernel_override == SBAMD_KERNEL_SPLITK && (h->kernel_param & 0xffff) > 0
+                        ? (h->kernel_param & 0xffff)
+                        : std::min<int64_t>(ceil_div(4 * int64_t(cus), tiles64), p.k / 128);
+    if (p.batch == 1 && (h->kernel_override == SBAMD_KERNEL_SPLITK || ((tiles64 * 2 <= cus && p.k >= 1024) || (tiles64 <= 2 * cus && p.k >= 2048))) && depth > 1) {
+      const int64_t k_chunk = 32 * ceil_div(p.k, 32 * depth);
+      depth = ceil_div(p.k, k_chunk);
+      if (depth > 1) {
+        const int64_t slice = p.m * p.n;
+        hipError_t e = ensure_scratch(h, size_t(slice) * depth * sizeof(float));
+        if (e != hipSuccess) return e;
+        GemmArgs16<float> gp;
+        gp.a = g.a, gp.b = g.b, gp.c = static_cast<float*>(h->scratch);
+        gp.m = g.m, gp.n = g.n, gp.k = g.k;
+        gp.lda = g.lda, gp.ldb = g.ldb, gp.ldc = p.m;
+        gp.stride_a = gp.stride_b = gp.stride_c = 0;
+        gp.batch = 1;
+        gp.tiles_m = gp.tiles_n = 0;
+        gp.vec_a = g.vec_a, gp.vec_b = g.vec_b;
+        gp.alpha = alpha, gp.beta = 0.0f, gp.beta_zero = 1;
+        gp.split_k = int32_t(depth), gp.k_chunk = k_chunk, gp.slice_stride = slice;
+        e = launch16<Tag, float, 64, 64, 32, 2, 2>(gp, p.ta, p.tb, h->stream);
+        if (e != hipSuccess) return e;
+        const int64_t grid = ceil_div(slice, 256);
+        hipLaunchKernelGGL((splitk_reduce16_kernel<TOut>), dim3((unsigned)grid), dim3(256), 0, h->stream,
+                           static_cast<const float*>(h->scratch), slice, int(depth), p.c, p.m, p.n, p.ldc, beta,
+                           g.beta_zero);
+        h->last_kernel = SBAMD_KERNEL_SPLITK;
+        h->last_depth = depth;
+        h->last_k_chunk = k_chunk;
+        return hipGetLastError();
+      }
+    }
+    if (h->kernel_override == SBAMD_KERNEL_SPLITK) family = SBAMD_KERNEL_SMALL;
   }
   h->last_kernel = family;
   if (family == SBAMD_KERNEL_HUGE) return launch16_dma<Tag, TOut>(g, p.ta, p.tb, h->stream);

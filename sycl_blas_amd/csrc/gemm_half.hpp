@@ -73,6 +73,10 @@ struct GemmArgs16 {
   int32_t vec_a, vec_b;
   float alpha, beta;
   int32_t beta_zero;
+  // K cut (register-staged kernels only): slice z covers k in [z*k_chunk, (z+1)*k_chunk)
+  // and writes alpha * (its partial sum) to c + z*slice_stride; 1 = no cut.
+  int32_t split_k;
+  int64_t k_chunk, slice_stride;
 };
 
 // Global -> registers -> LDS for one operand tile (BMN x BK, 16-bit elements).
@@ -179,9 +183,19 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
   int tm, tn;
   tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
   const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
-  const uint16_t* a = g.a + int64_t(z) * g.stride_a;
-  const uint16_t* b = g.b + int64_t(z) * g.stride_b;
-  TOut* c = g.c + int64_t(z) * g.stride_c;
+  const uint16_t* a = g.a;
+  const uint16_t* b = g.b;
+  TOut* c = g.c;
+  int64_t k_begin = 0, k_end = g.k;
+  if (g.split_k > 1) {
+    k_begin = int64_t(z) * g.k_chunk;
+    k_end = k_begin + g.k_chunk < g.k ? k_begin + g.k_chunk : g.k;
+    c += int64_t(z) * g.slice_stride;
+  } else {
+    a += int64_t(z) * g.stride_a;
+    b += int64_t(z) * g.stride_b;
+    c += int64_t(z) * g.stride_c;
+  }
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -194,18 +208,18 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
   LoadA la;
   LoadB lb;
   const bool fast = (m0 + BM <= g.m) && (n0 + BN <= g.n) && g.vec_a && g.vec_b;
-  const int nk = int((g.k + BK - 1) / BK);
+  const int nk = k_end > k_begin ? int((k_end - k_begin + BK - 1) / BK) : 0;
   const int frag_mn = lane & 31, frag_h = lane >> 5;
   const int a_row = wm * WTM + frag_mn;
 
   auto load_tile = [&](int kt) {
-    const int64_t k0 = int64_t(kt) * BK;
-    if (fast && k0 + BK <= g.k) {
+    const int64_t k0 = k_begin + int64_t(kt) * BK;
+    if (fast && k0 + BK <= k_end) {
       la.load_fast(a, g.lda, m0, k0, tid);
       lb.load_fast(b, g.ldb, n0, k0, tid);
     } else {
-      la.load_edge(a, g.lda, m0, g.m, k0, g.k, tid);
-      lb.load_edge(b, g.ldb, n0, g.n, k0, g.k, tid);
+      la.load_edge(a, g.lda, m0, g.m, k0, k_end, tid);
+      lb.load_edge(b, g.ldb, n0, g.n, k0, k_end, tid);
     }
   };
 
@@ -264,6 +278,25 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
       }
     }
   }
+}
+
+// Sum of the K slabs (fp32 cube, slabs added in index order) + beta * C, rounded once to
+// the output type: the 16-bit twin of splitk_reduce_kernel.
+template <typename TOut>
+__global__ void __launch_bounds__(256)
+    splitk_reduce16_kernel(const float* __restrict__ cube, int64_t slice_stride, int depth, TOut* c, int64_t m, int64_t n,
+                           int64_t ldc, float beta, int beta_zero) {
+  const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= m * n) return;
+  const float* src = cube + idx;
+  float sum = *src;
+  for (int d = 1; d < depth; ++d) sum = sum + src[int64_t(d) * slice_stride];
+  TOut* p = c + (idx % m) + (idx / m) * ldc;
+  if (!beta_zero) {
+    const float bc = beta * load_out(p);
+    sum = sum + bc;
+  }
+  store_out(p, sum);
 }
 
 // C = beta * C for 16-bit output (alpha == 0 path): multiply in fp32, round once.

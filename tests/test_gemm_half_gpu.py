@@ -46,7 +46,7 @@ def make_inputs(rng, count, storage):
     return bits, from_bf16_bits(bits)
 
 
-def run_case(h, pair, m, n, k, ta, tb, alpha, beta, ldm=1, offset=0, batch=1, family=_lib.KERNEL_AUTO):
+def run_case(h, pair, m, n, k, ta, tb, alpha, beta, ldm=1, offset=0, batch=1, family=_lib.KERNEL_AUTO, param=0):
     storage, out_name = pair
     rng = seeded("half", pair, m, n, k, ta, tb, alpha, beta, ldm, offset, batch)
     lda = (k if ta != "n" else m) * ldm
@@ -68,7 +68,7 @@ def run_case(h, pair, m, n, k, ta, tb, alpha, beta, ldm=1, offset=0, batch=1, fa
                              a_off=offset, b_off=offset, c_off=offset)
     assert st == 0
 
-    h.set_kernel(family)
+    h.set_kernel(family, param)
     a_g = helper.allocate(h, storage, a_bits.size)
     b_g = helper.allocate(h, storage, b_bits.size)
     c_g = helper.allocate(h, out_name, c_dev.size)
@@ -172,6 +172,22 @@ def test_direct_to_lds_family(sb_handle, pair):
     # ... but an odd M is fine when K is A's contiguous index
     run_case(sb_handle, pair, 257, 256, 128, "t", "n", 1.0, 1.0, family=fam)
     assert sb_handle.last_kernel() == fam
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_k_cut_for_thin_shapes(sb_handle, pair):
+    # Few tiles and a long K: the K range is cut over extra workgroups, partial sums in fp32.
+    for (m, n, k), ta, tb in itertools.product([(48, 130, 2048), (2, 64, 4100), (100, 7, 1537), (300, 500, 2048)], "nt", "nt"):
+        run_case(sb_handle, pair, m, n, k, ta, tb, 1.5, 0.5)
+        assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK and sb_handle.last_splitk()[0] > 1
+        run_case(sb_handle, pair, m, n, k, ta, tb, -2.0, 0.0, ldm=2, offset=8)
+    # a pinned depth on a shape that would not be cut by itself
+    h = sb_handle
+    h.set_kernel(_lib.KERNEL_SPLITK, 3)
+    try:
+        run_case(h, pair, 200, 150, 333, "n", "t", 1.0, 1.0, family=_lib.KERNEL_SPLITK, param=3)
+    finally:
+        h.set_kernel(_lib.KERNEL_AUTO)
 
 
 def test_alpha_zero_and_beta_zero_on_half_output(sb_handle):

@@ -66,7 +66,7 @@ def main(path):
             continue
         data.append((dt, tile, depth, m, n, k, us))
     dtype = data[0][0]
-    x0 = np.array([0.035, 0.041, 0.057, 0.074, 0.078, 0.146, 0.24 if False else 0.12, 1.5, 5.0, 3.0, 0.03])
+    x0 = np.array([0.035, 0.041, 0.057, 0.074, 0.078, 0.146, 0.12, 1.5, 5.0, 3.0, 0.03])
     if dtype == "double":
         x0[:7] *= 1.8
 

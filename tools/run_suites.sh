@@ -18,6 +18,9 @@ run gemm gemm_square_all_trans.csv float gemm_trans_f32
 run gemm gemm_square_all_trans.csv double gemm_trans_f64
 run gemm gemm_rectangular.csv float gemm_rect_f32
 run gemm gemm_headline.csv float gemm_headline_f32
+run gemm gemm_transformer_shapes.csv float gemm_transformer_f32
+run gemm gemm_transformer_shapes.csv bf16 gemm_transformer_bf16
+run gemm_batched gemm_batched_reference_shapes.csv float gemm_batched_reference_shapes_f32
 run gemm_batched gemm_batched.csv float gemm_batched_f32
 run gemm_batched_strided gemm_batched_strided.csv float gemm_batched_strided_f32
 run symm symm_square.csv float symm_f32
