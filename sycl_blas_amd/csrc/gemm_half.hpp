@@ -93,13 +93,27 @@ struct TileLoader16 {
 
   u16x8 reg[NV];
 
-  __device__ inline void load_fast(const uint16_t* __restrict__ x, int64_t ld, int64_t mn0, int64_t k0, int tid) {
+  // 16-byte loads.  Tiles that hang over the matrix edge use them too: a vector whose M/N
+  // index lies past the edge is pointed at the last valid row (K-contiguous operand) or the
+  // last valid vector (M/N-contiguous operand; the caller guarantees mn_lim % 8 == 0 there,
+  // so no vector straddles the edge).  What it loads only feeds C elements never stored.
+  __device__ inline void load_fast(const uint16_t* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim, int64_t k0,
+                                   int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
-      const uint16_t* p = KMAJOR ? (x + (k0 + col) + (mn0 + row) * ld) : (x + (mn0 + col) + (k0 + row) * ld);
+      const uint16_t* p;
+      if (KMAJOR) {
+        int64_t mn = mn0 + row;
+        mn = mn < mn_lim ? mn : mn_lim - 1;
+        p = x + (k0 + col) + mn * ld;
+      } else {
+        int64_t mn = mn0 + col;
+        mn = mn < mn_lim ? mn : mn_lim - V;
+        p = x + mn + (k0 + row) * ld;
+      }
       reg[i] = *reinterpret_cast<const u16x8*>(p);
     }
   }
@@ -207,7 +221,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
 
   LoadA la;
   LoadB lb;
-  const bool fast = (m0 + BM <= g.m) && (n0 + BN <= g.n) && g.vec_a && g.vec_b;
+  const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
+  const bool clampable = (TA || g.m % 8 == 0) && (!TB || g.n % 8 == 0);
+  const bool fast = (interior || clampable) && g.vec_a && g.vec_b;
   const int nk = k_end > k_begin ? int((k_end - k_begin + BK - 1) / BK) : 0;
   const int frag_mn = lane & 31, frag_h = lane >> 5;
   const int a_row = wm * WTM + frag_mn;
@@ -215,8 +231,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
   auto load_tile = [&](int kt) {
     const int64_t k0 = k_begin + int64_t(kt) * BK;
     if (fast && k0 + BK <= k_end) {
-      la.load_fast(a, g.lda, m0, k0, tid);
-      lb.load_fast(b, g.ldb, n0, k0, tid);
+      la.load_fast(a, g.lda, m0, g.m, k0, tid);
+      lb.load_fast(b, g.ldb, n0, g.n, k0, tid);
     } else {
       la.load_edge(a, g.lda, m0, g.m, k0, k_end, tid);
       lb.load_edge(b, g.ldb, n0, g.n, k0, k_end, tid);
