@@ -114,6 +114,14 @@ int sbamd_last_kernel(sbamd_handle_t h);
  * checker needs it to reproduce the result exactly. */
 int sbamd_last_splitk(sbamd_handle_t h, int64_t* depth, int64_t* k_chunk);
 
+/* How the last _trsm call on this handle was carried out: `diag` = launches of the
+ * kernel that solves a whole diagonal super-block (up to 128 rows) at once, `panel` =
+ * launches that apply the updates of many 16-wide blocks to a panel in one pass.  Both
+ * are 0 when the call went block by block, GEMM call for GEMM call, as
+ * src/interface/trsm_interface.hpp:227-380 does.  The result is the same bit for bit
+ * either way; tests use the counts to know which route they exercised. */
+int sbamd_last_trsm_launches(sbamd_handle_t h, int64_t* diag, int64_t* panel);
+
 /* ------------------------------------------------------------------ events */
 
 /* The reference returns std::vector<sycl::event> from every call and takes a

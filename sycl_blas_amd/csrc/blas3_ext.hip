@@ -81,6 +81,110 @@ __global__ void __launch_bounds__(64)
     for (int j = 0; j < B; ++j) inv[blk * B * B + j * B + i] = local[j + i * B];
 }
 
+// Solves a diagonal super-block of up to 128 rows (columns on the right side) of the
+// triangular system in one launch: the 16-wide block sweep of the reference restricted
+// to the super-block -- X_i = alpha_i * inv(A_ii) * B_i, then B_j <- -(A_ji * X_i) + beta_i * B_j
+// for the blocks j still to come -- with every sum the k-ordered fma chain, and every
+// product / sum rounding, of the GEMM calls it replaces (trsm_interface.hpp:227-380).
+// A workgroup owns a slab of 32 columns (rows on the right side) of the panel, keeps it
+// in LDS from the first block to the last and writes the solved slab into X.
+//
+// The panel is indexed (p, q): p runs along the solved dimension inside the super-block,
+// q along the free one.  LEFT:  element (p, q) is B[(o + p) + q * ldb];  right: B[q + (o + p) * ldb].
+// W(p, k), the coefficient of X[k] in row p, is A[(o + p) + (o + k) * lda], or with WT the
+// transposed access A[(o + k) + (o + p) * lda]  (WT = trans on the left, !trans on the right);
+// the inverted diagonal blocks are read the same way.
+template <typename T, bool LEFT, bool WT, bool FORWARD>
+__global__ void __launch_bounds__(256)
+    trsm_diag_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ inv, const T* __restrict__ B,
+                     int64_t ldb, T* __restrict__ X, int64_t ldx, int64_t o, int s, int64_t nq, T alpha,
+                     int first_blk) {
+  constexpr int CW = 32, SM = 128, BS = 16;
+  __shared__ T V[SM][CW + 1];
+  __shared__ T Xi[BS][CW + 1];
+  __shared__ T Wi[BS][BS + 1];
+  __shared__ T Ws[SM][BS + 1];
+  const int t = threadIdx.x;
+  const int64_t q0 = int64_t(blockIdx.x) * CW;
+  const int total = s * CW;
+  for (int idx = t; idx < total; idx += 256) {
+    const int p = LEFT ? idx % s : idx / CW;  // lanes along the contiguous index
+    const int q = LEFT ? idx / s : idx % CW;
+    T v = T(0);
+    if (q0 + q < nq) v = LEFT ? B[(o + p) + (q0 + q) * ldb] : B[(q0 + q) + (o + p) * ldb];
+    V[p][q] = v;
+  }
+  const int q = t % CW, pr = t / CW;  // 8 row groups
+  const int nblk = (s + BS - 1) / BS;
+  for (int step = 0; step < nblk; ++step) {
+    const int b = FORWARD ? step : nblk - 1 - step;
+    const int pb = b * BS;
+    const int cb = s - pb < BS ? s - pb : BS;
+    const int rem0 = FORWARD ? pb + BS : 0;  // rows still to come
+    const int rem1 = FORWARD ? s : pb;
+    {
+      const T* blk = inv + (o / BS + b) * (BS * BS);  // column-major: blk[r + c * 16]
+      const int r = t % BS, c = t / BS;
+      if (WT) Wi[c][r] = blk[t];
+      else Wi[r][c] = blk[t];
+      const int nrem = rem1 - rem0;
+      if (nrem > 0) {
+        if (WT) {
+          for (int idx = t; idx < nrem * BS; idx += 256) {
+            const int k = idx % BS, p = rem0 + idx / BS;
+            if (k < cb) Ws[p][k] = A[(o + pb + k) + (o + p) * lda];
+          }
+        } else {
+          for (int idx = t; idx < nrem * cb; idx += 256) {
+            const int p = rem0 + idx % nrem, k = idx / nrem;
+            Ws[p][k] = A[(o + p) + (o + pb + k) * lda];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int pp = pr; pp < cb; pp += 8) {
+      T acc = T(0);
+      for (int k = 0; k < cb; ++k) acc = fma_rn(Wi[pp][k], V[pb + k][q], acc);
+      Xi[pp][q] = (b == first_blk) ? alpha * acc : acc;
+    }
+    __syncthreads();
+    T xk[BS];
+#pragma unroll
+    for (int k = 0; k < BS; ++k) xk[k] = k < cb ? Xi[k][q] : T(0);
+    for (int pp = pr; pp < cb; pp += 8) V[pb + pp][q] = Xi[pp][q];
+    if (cb == BS) {
+      for (int p = rem0 + pr; p < rem1; p += 8) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < BS; ++k) acc = fma_rn(Ws[p][k], xk[k], acc);
+        T bc = V[p][q];
+        if (b == first_blk) bc = alpha * bc;
+        const T neg = T(-1) * acc;
+        V[p][q] = neg + bc;
+      }
+    } else {
+      for (int p = rem0 + pr; p < rem1; p += 8) {
+        T acc = T(0);
+        for (int k = 0; k < cb; ++k) acc = fma_rn(Ws[p][k], Xi[k][q], acc);
+        T bc = V[p][q];
+        if (b == first_blk) bc = alpha * bc;
+        const T neg = T(-1) * acc;
+        V[p][q] = neg + bc;
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = t; idx < total; idx += 256) {
+    const int p = LEFT ? idx % s : idx / CW;
+    const int qq = LEFT ? idx / s : idx % CW;
+    if (q0 + qq < nq) {
+      if (LEFT) X[(o + p) + (q0 + qq) * ldx] = V[p][qq];
+      else X[(q0 + qq) + (o + p) * ldx] = V[p][qq];
+    }
+  }
+}
+
 template <typename T>
 struct Api;
 template <>
@@ -97,6 +201,69 @@ struct Api<double> {
     return sbamd_dgemm(h, ta, tb, m, n, k, al, a, lda, b, ldb, be, c, ldc);
   }
 };
+
+// ---- chunked-accumulation GEMM launch (see gemm_chunked_kernel) ----------------
+constexpr int TRSM_BS = 16;  // the reference's diagonal block (trsm_interface.hpp:169)
+
+template <typename T, int BM, int BN, int OCC, bool TA, bool TB, bool REVERSE>
+hipError_t launch_chunked_one(GemmArgs<T> g, hipStream_t stream) {
+  using K = GemmTile<T, BM, BN, TRSM_BS, 2, 2, TA, TB>;
+  auto kernel = gemm_chunked_kernel<T, BM, BN, TRSM_BS, 2, 2, TA, TB, REVERSE, OCC>;
+  static PerDeviceOnce lds_limit;
+  hipError_t e = lds_limit.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(K::LDS_BYTES));
+  });
+  if (e != hipSuccess) return e;
+  g.tiles_m = int32_t((g.m + BM - 1) / BM);
+  g.tiles_n = int32_t((g.n + BN - 1) / BN);
+  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(K::NT), K::LDS_BYTES, stream, g);
+  return hipGetLastError();
+}
+
+template <typename T, int BM, int BN, int OCC>
+hipError_t launch_chunked_tile(const GemmArgs<T>& g, bool ta, bool tb, bool reverse, hipStream_t stream) {
+  // the solver multiplies op(A) * X or X * op(A): at most one operand is transposed
+  if (ta && tb) return hipErrorInvalidValue;
+  if (reverse) {
+    if (ta) return launch_chunked_one<T, BM, BN, OCC, true, false, true>(g, stream);
+    if (tb) return launch_chunked_one<T, BM, BN, OCC, false, true, true>(g, stream);
+    return launch_chunked_one<T, BM, BN, OCC, false, false, true>(g, stream);
+  }
+  if (ta) return launch_chunked_one<T, BM, BN, OCC, true, false, false>(g, stream);
+  if (tb) return launch_chunked_one<T, BM, BN, OCC, false, true, false>(g, stream);
+  return launch_chunked_one<T, BM, BN, OCC, false, false, false>(g, stream);
+}
+
+// C <- the k / 16 successive updates  C <- alpha * op(A)[:, q] * op(B)[q, :] + beta_q * C  (beta_0 = beta,
+// then 1), chunks ascending or, with `reverse`, descending.  The caller has checked the operands.
+template <typename T>
+hipError_t launch_chunked(Handle* h, bool ta, bool tb, bool reverse, int64_t m, int64_t n, int64_t k, T alpha,
+                          const T* a, int64_t lda, const T* b, int64_t ldb, T beta, T* c, int64_t ldc) {
+  GemmArgs<T> g{};
+  g.a = a;
+  g.b = b;
+  g.c = c;
+  g.m = m;
+  g.n = n;
+  g.k = k;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = ldc;
+  g.batch = 1;
+  g.split_k = 1;
+  g.k_chunk = k;
+  g.vec_a = g.vec_b = 1;
+  g.alpha = alpha;
+  g.beta = beta;
+  g.beta_zero = (beta == T(0)) ? 1 : 0;
+  const int64_t tiles128 = ((m + 127) / 128) * ((n + 127) / 128);
+  if (tiles128 * 2 >= h->compute_units)
+    return launch_chunked_tile<T, 128, 128, sizeof(T) == 4 ? 2 : 1>(g, ta, tb, reverse, h->stream);
+  return launch_chunked_tile<T, 64, 64, 2>(g, ta, tb, reverse, h->stream);
+}
 
 int hip_fail(Handle* h, hipError_t e, const char* what) {
   h->last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -132,6 +299,178 @@ int symm(sbamd_handle_t hh, char side, char uplo, int64_t m, int64_t n, T alpha,
   return side == 'l' ? Api<T>::gemm(hh, 'n', 'n', m, n, k, alpha, full, k, b, ldb, beta, c, ldc)
                      : Api<T>::gemm(hh, 'n', 'n', m, n, k, alpha, b, ldb, full, k, beta, c, ldc);
 }
+
+// The block sweep of the triangular solve.  The reference walks the 16-wide diagonal
+// blocks in order; at block i it forms X_i = inv(A_ii) * B_i and then subtracts
+// A_(rest,i) * X_i from every block still to come, one GEMM call each
+// (trsm_interface.hpp:227-251 left/forward, :267-292 left/backward, :312-337
+// right/backward, :354-380 right/forward).  An element of a later block therefore sees
+// the updates of the earlier blocks one after the other, in sweep order.
+//
+// Here the same per-element sequence is produced with far fewer passes over B: the block
+// range is halved recursively, the first half is solved, and all of its updates to the
+// second half go out as ONE chunked-accumulation launch (k = the size of the first half,
+// folded into the running tile every 16), before the second half is solved.  Every
+// element still receives the same products in the same order with the same roundings, so
+// the result equals the block-by-block sweep bit for bit; the work on B drops from
+// O(K/16) passes to O(log K).  Operands the chunked kernel cannot take (unaligned, or an
+// edge a 16-byte vector would straddle) fall back to the block-by-block sweep.
+template <typename T>
+struct TrsmSweep {
+  sbamd_handle_t hh;
+  Handle* h;
+  bool left, tr, forward;
+  int64_t M, N;
+  T alpha;
+  const T* A;
+  int64_t lda;
+  T* B;
+  int64_t ldb;
+  T* X;
+  int64_t ldx;
+  const T* invA;
+
+  static constexpr int64_t bs = TRSM_BS;
+  static constexpr int64_t super = 128;  // rows one trsm_diag_kernel launch solves
+  int64_t first = 0;     // the block whose calls carry alpha (-1: already spent)
+  bool chunked = false;  // multi-block updates may use the chunked kernel
+  bool fused = false;    // diagonal super-blocks go to trsm_diag_kernel
+  int64_t panel_launches = 0, diag_launches = 0;
+
+  // All blocks of [lo, hi) (at most `super` rows) in one launch.
+  int diag(int64_t lo, int64_t hi) {
+    const int64_t nq = left ? N : M;
+    const unsigned grid = unsigned((nq + 31) / 32);
+    const int fb = (first >= lo && first < hi) ? int((first - lo) / bs) : -1;
+    const bool wt = left ? tr : !tr;
+    const int s = int(hi - lo);
+#define SBAMD_DIAG(L, W, F)                                                                                       \
+  hipLaunchKernelGGL((trsm_diag_kernel<T, L, W, F>), dim3(grid), dim3(256), 0, h->stream, A, lda, invA, B, ldb, X, \
+                     ldx, lo, s, nq, alpha, fb)
+    if (left) {
+      if (wt) { if (forward) SBAMD_DIAG(true, true, true); else SBAMD_DIAG(true, true, false); }
+      else    { if (forward) SBAMD_DIAG(true, false, true); else SBAMD_DIAG(true, false, false); }
+    } else {
+      if (wt) { if (forward) SBAMD_DIAG(false, true, true); else SBAMD_DIAG(false, true, false); }
+      else    { if (forward) SBAMD_DIAG(false, false, true); else SBAMD_DIAG(false, false, false); }
+    }
+#undef SBAMD_DIAG
+    ++diag_launches;
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SBAMD_OK : hip_fail(h, e, "trsm diagonal launch");
+  }
+
+  int64_t extent() const { return left ? M : N; }
+
+  // X_i = alpha_i * inv(A_ii) * B_i   (or B_i * inv(A_ii) on the right)
+  int leaf(int64_t i, int64_t cb) {
+    const T al = (i == first) ? alpha : T(1);
+    const char tc = tr ? 't' : 'n';
+    if (left) return Api<T>::gemm(hh, tc, 'n', cb, N, cb, al, invA + i * bs, bs, B + i, ldb, T(0), X + i, ldx);
+    return Api<T>::gemm(hh, 'n', tc, M, cb, cb, al, B + i * ldb, ldb, invA + i * bs, bs, T(0), X + i * ldx, ldx);
+  }
+
+  // Blocks [d0, d1) of B  -=  (the A block between them and the solved blocks [s0, s1)) * X[s0, s1)
+  int update(int64_t s0, int64_t s1, int64_t d0, int64_t d1) {
+    if (d1 <= d0) return SBAMD_OK;
+    const bool has_first = first >= s0 && first < s1;
+    const T beta = has_first ? alpha : T(1);
+    const char tc = tr ? 't' : 'n';
+    const int64_t k = s1 - s0;
+    const T* ablk = left ? A + (!tr ? d0 + s0 * lda : s0 + d0 * lda) : A + (!tr ? s0 + d0 * lda : d0 + s0 * lda);
+    if (k <= bs || !chunked) {
+      if (left) return Api<T>::gemm(hh, tc, 'n', d1 - d0, N, k, T(-1), ablk, lda, X + s0, ldx, beta, B + d0, ldb);
+      return Api<T>::gemm(hh, 'n', tc, M, d1 - d0, k, T(-1), X + s0 * ldx, ldx, ablk, lda, beta, B + d0 * ldb, ldb);
+    }
+    ++panel_launches;
+    hipError_t e = left ? launch_chunked<T>(h, tr, false, !forward, d1 - d0, N, k, T(-1), ablk, lda, X + s0, ldx, beta,
+                                            B + d0, ldb)
+                        : launch_chunked<T>(h, false, tr, !forward, M, d1 - d0, k, T(-1), X + s0 * ldx, ldx, ablk, lda,
+                                            beta, B + d0 * ldb, ldb);
+    return e == hipSuccess ? SBAMD_OK : hip_fail(h, e, "trsm update launch");
+  }
+
+  static int64_t split_blocks(int64_t nb) {  // largest power of two below nb
+    int64_t p = 1;
+    while (p * 2 < nb) p *= 2;
+    return p;
+  }
+
+  // [lo, hi): lo is a multiple of 16; hi is one too or the end of the matrix.
+  int solve(int64_t lo, int64_t hi) {
+    const int64_t nb = (hi - lo + bs - 1) / bs;
+    if (fused && hi - lo <= super) return diag(lo, hi);
+    if (nb <= 1) return leaf(lo, hi - lo);
+    int st;
+    if (forward) {
+      const int64_t mid = lo + split_blocks(nb) * bs;
+      if ((st = solve(lo, mid)) != SBAMD_OK) return st;
+      if ((st = update(lo, mid, mid, hi)) != SBAMD_OK) return st;
+      return solve(mid, hi);
+    }
+    const int64_t mid = hi - split_blocks(nb) * bs;  // backward ranges hold whole blocks
+    if ((st = solve(mid, hi)) != SBAMD_OK) return st;
+    if ((st = update(mid, hi, lo, mid)) != SBAMD_OK) return st;
+    return solve(lo, mid);
+  }
+
+  int run() {
+    constexpr int V = 16 / sizeof(T);
+    const int64_t K = extent();
+    const bool aligned = reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0 &&
+                         lda % V == 0 && ldx % V == 0;
+    // op(A) K-major needs nothing more; an M/N-major operand must not straddle its edge
+    chunked = aligned && (left ? (tr || M % V == 0) : (M % V == 0 && (!tr || N % V == 0)));
+    // alpha == 0 turns the first block's GEMM calls into the reference's scaling path
+    // (gemm_interface.hpp:112-139): leave that to the GEMM entry point.
+    fused = !(alpha == T(0));
+    if (!chunked) {
+      // The reference's sweep: one update call per 16-wide block over everything still to
+      // come; the blocks of a super-block are solved together first when that is allowed
+      // (an element outside the super-block sees the same updates in the same order).
+      const int64_t group = fused ? super : bs;
+      if (forward) {
+        first = 0;
+        for (int64_t lo = 0; lo < K; lo += group) {
+          const int64_t hi = std::min(K, lo + group);
+          int st = solve(lo, hi);
+          if (st != SBAMD_OK) return st;
+          for (int64_t i = lo; i < hi && hi < K; i += bs)
+            if ((st = update(i, i + bs, hi, K)) != SBAMD_OK) return st;
+        }
+      } else {
+        const int64_t special = (K % bs == 0) ? bs : (K % bs);
+        first = K - special;
+        for (int64_t hi = K; hi > 0;) {
+          // whole blocks below the ragged one: group boundaries stay multiples of 16
+          const int64_t lo = hi - group > 0 ? (hi - group + bs - 1) / bs * bs : 0;
+          int st = solve(lo, hi);
+          if (st != SBAMD_OK) return st;
+          if (lo > 0)
+            for (int64_t i = (hi - 1) / bs * bs; i >= lo; i -= bs)
+              if ((st = update(i, std::min(i + bs, hi), 0, lo)) != SBAMD_OK) return st;
+          hi = lo;
+        }
+      }
+      return SBAMD_OK;
+    }
+    if (forward) {
+      first = 0;
+      return solve(0, K);
+    }
+    // Backward sweeps start at the ragged block, if there is one: it is handled on its own
+    // (its update has k < 16), the blocks below it are whole.
+    const int64_t special = (K % bs == 0) ? bs : (K % bs);
+    first = K - special;
+    if (special == bs) return solve(0, K);
+    int st = leaf(first, special);
+    if (st != SBAMD_OK || first == 0) return st;
+    if ((st = update(first, K, 0, first)) != SBAMD_OK) return st;
+    const int64_t top = first;
+    first = -1;
+    return solve(0, top);
+  }
+};
 
 template <typename T>
 int trsm(sbamd_handle_t hh, char side, char uplo, char trans, char diag, int64_t M, int64_t N, T alpha, const T* A,
@@ -174,54 +513,12 @@ int trsm(sbamd_handle_t hh, char side, char uplo, char trans, char diag, int64_t
   e = hipMemcpyAsync(X, B, size_t(b_elems) * sizeof(T), hipMemcpyDeviceToDevice, h->stream);
   if (e != hipSuccess) return hip_fail(h, e, "trsm copy");
   const int64_t ldx = ldb;
-  const char tc = tr ? 't' : 'n';
-  int st = SBAMD_OK;
-#define GEMM(...)                                     \
-  do {                                                \
-    st = Api<T>::gemm(hh, __VA_ARGS__);               \
-    if (st != SBAMD_OK) return st;                    \
-  } while (0)
-
-  if (left) {
-    if ((upper && tr) || (!upper && !tr)) {  // forward over block rows, :227-251
-      for (int64_t i = 0; i < M; i += bs) {
-        const int64_t cb = std::min(M - i, bs);
-        GEMM(tc, 'n', cb, N, cb, (i == 0) ? alpha : T(1), invA + i * bs, bs, B + i, ldb, T(0), X + i, ldx);
-        if (i + bs >= M) break;
-        const int64_t off = !tr ? ((i + bs) + i * lda) : (i + (bs + i) * lda);
-        GEMM(tc, 'n', M - i - bs, N, bs, T(-1), A + off, lda, X + i, ldx, (i == 0) ? alpha : T(1), B + i + bs, ldb);
-      }
-    } else {  // backward, :267-292
-      const int64_t special = (M % bs == 0) ? bs : (M % bs);
-      const int64_t start = M - special;
-      for (int64_t i = start; i >= 0; i -= bs) {
-        const int64_t cb = (i == start) ? special : bs;
-        GEMM(tc, 'n', cb, N, cb, (i == start) ? alpha : T(1), invA + i * bs, bs, B + i, ldb, T(0), X + i, ldx);
-        if (i - bs < 0) break;
-        GEMM(tc, 'n', i, N, cb, T(-1), A + (!tr ? (i * lda) : i), lda, X + i, ldx, (i == start) ? alpha : T(1), B, ldb);
-      }
-    }
-  } else {
-    if ((upper && tr) || (!upper && !tr)) {  // backward over block columns, :312-337
-      const int64_t special = (N % bs == 0) ? bs : (N % bs);
-      const int64_t start = N - special;
-      for (int64_t i = start; i >= 0; i -= bs) {
-        const int64_t cb = (i == start) ? special : bs;
-        GEMM('n', tc, M, cb, cb, (i == start) ? alpha : T(1), B + i * ldb, ldb, invA + i * bs, bs, T(0), X + i * ldx, ldx);
-        if (i - bs < 0) break;
-        GEMM('n', tc, M, i, cb, T(-1), X + i * ldx, ldx, A + (!tr ? i : (i * lda)), lda, (i == start) ? alpha : T(1), B, ldb);
-      }
-    } else {  // forward, :354-380
-      for (int64_t i = 0; i < N; i += bs) {
-        const int64_t cb = std::min(N - i, bs);
-        GEMM('n', tc, M, cb, cb, (i == 0) ? alpha : T(1), B + i * ldb, ldb, invA + i * bs, bs, T(0), X + i * ldx, ldx);
-        if (i + bs > N) break;  // when i + bs == N the call below has no columns and returns at once
-        const int64_t off = !tr ? (i + (bs + i) * lda) : ((i + bs) + i * lda);
-        GEMM('n', tc, M, N - i - bs, bs, T(-1), X + i * ldx, ldx, A + off, lda, (i == 0) ? alpha : T(1), B + (i + bs) * ldb, ldb);
-      }
-    }
-  }
-#undef GEMM
+  const bool forward = left ? ((upper && tr) || (!upper && !tr)) : !((upper && tr) || (!upper && !tr));
+  TrsmSweep<T> sw{hh, h, left, tr, forward, M, N, alpha, A, lda, B, ldb, X, ldx, invA};
+  const int st = sw.run();
+  h->last_trsm_diag = sw.diag_launches;
+  h->last_trsm_panel = sw.panel_launches;
+  if (st != SBAMD_OK) return st;
   // the result travels back into B (:384-389)
   e = hipMemcpyAsync(B, X, size_t(b_elems) * sizeof(T), hipMemcpyDeviceToDevice, h->stream);
   if (e != hipSuccess) return hip_fail(h, e, "trsm copy back");

@@ -29,14 +29,12 @@ template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, 
 hipError_t launch_one(const GemmArgs<T>& g, int64_t nz, hipStream_t stream) {
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
   auto kernel = gemm_mfma_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       int(K::LDS_BYTES));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_limit;
+  hipError_t e = lds_limit.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(K::LDS_BYTES));
+  });
+  if (e != hipSuccess) return e;
   const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * nz;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   // A K range that fits one K step never touches the second LDS buffer: ask for

@@ -11,13 +11,12 @@ hipError_t launch16_one(const GemmArgs16<TOut>& g, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr size_t lds = 2 * size_t(TileLoader16<BM, BK, NT, TA>::ELEMS + TileLoader16<BN, BK, NT, !TB>::ELEMS) * 2;
   auto kernel = gemm_mfma16_kernel<Tag, TOut, BM, BN, BK, WM, WN, TA, TB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_limit;
+  hipError_t e = lds_limit.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(lds));
+  });
+  if (e != hipSuccess) return e;
   const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * (g.split_k > 1 ? g.split_k : g.batch);
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds, stream, g);
@@ -39,13 +38,12 @@ hipError_t launch16(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream) {
 template <typename Tag, typename TOut, bool TA, bool TB>
 hipError_t launch16_dma_one(const GemmArgs16<TOut>& g, hipStream_t stream) {
   auto kernel = gemm_mfma16_ring_kernel<Tag, TOut, TA, TB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_limit;
+  hipError_t e = lds_limit.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               RING_LDS_BYTES);
+  });
+  if (e != hipSuccess) return e;
   const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * g.batch;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(DMA_NT), RING_LDS_BYTES, stream, g);

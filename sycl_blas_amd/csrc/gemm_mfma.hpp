@@ -170,9 +170,10 @@ struct TileLoader {
     }
   }
 
-  // Load the tile the pointers address, then move them one K step on.
+  // Load the tile the pointers address, then move them one K step on (DIR = -1: back).
+  template <int DIR = 1>
   __device__ inline void load_fast(int64_t ld) {
-    const int64_t step = KMAJOR ? int64_t(BK) : int64_t(BK) * ld;
+    const int64_t step = DIR * (KMAJOR ? int64_t(BK) : int64_t(BK) * ld);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(ptr[i]);
@@ -486,6 +487,82 @@ struct GemmBody {
     }
   }
 
+  // ---- chunked accumulation: every K step (BK = one chunk) is its own product,
+  // folded into the running tile before the next one starts:
+  //     run <- alpha * (A_chunk * B_chunk) + run        (product and sum rounded apart)
+  // which is, element for element and rounding for rounding, what a sequence of
+  // k / BK separate GEMM calls with beta = 1 on the same C computes -- in one pass
+  // over C instead of k / BK passes.  REVERSE walks the chunks from the high end of
+  // K down (k inside a chunk still ascends).  Needs k % BK == 0, k >= BK and
+  // operands the vector path can load.
+  template <bool REVERSE>
+  __device__ inline void run_chunked(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
+                                     SBAMD_LDS T* smem, int tid, int a_mn, int b_mn,
+                                     typename M::acc_t (&run)[K::MI][K::NI]) {
+    constexpr int DIR = REVERSE ? -1 : 1;
+    const int lane = tid & 63;
+    const int nfull = int(g.k / BK);
+    constexpr int NW = LoadA::NWRITE + LoadB::NWRITE;
+    constexpr int NL = LoadA::NV + LoadB::NV;
+    SBAMD_LDS T* const buf0 = smem;
+    SBAMD_LDS T* const buf1 = smem + K::STAGE_ELEMS;
+    const T alpha = g.alpha;
+    auto fold = [&]() {
+#pragma unroll
+      for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+          for (int r = 0; r < M::NACC; ++r) {
+            const T t = alpha * acc[i][j][r];
+            run[i][j][r] = t + run[i][j][r];
+            acc[i][j][r] = T(0);
+          }
+    };
+
+    const int64_t k_first = REVERSE ? g.k - BK : 0;
+    la.init_fast(a, g.lda, m0, g.m, k_first, tid);
+    lb.init_fast(b, g.ldb, n0, g.n, k_first, tid);
+    la.template load_fast<DIR>(g.lda);
+    lb.template load_fast<DIR>(g.ldb);
+    la.store(buf0, tid);
+    lb.store(buf0 + K::A_ELEMS, tid);
+    if (nfull > 1) {
+      la.template load_fast<DIR>(g.lda);
+      lb.template load_fast<DIR>(g.ldb);
+    }
+    __syncthreads();
+    frag_a_t fa;
+    frag_b_t fb;
+    fetch_group(buf0, buf0 + K::A_ELEMS, 0, a_mn, b_mn, lane, fa[0], fb[0]);
+
+    int kt = 0;
+    for (; kt + 2 < nfull; ++kt) {
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
+      la.store(nxt, tid);
+      lb.store(nxt + K::A_ELEMS, tid);
+      la.template load_fast<DIR>(g.lda);
+      lb.template load_fast<DIR>(g.ldb);
+      pipelined_step<true, NW, NL>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
+      fold();
+    }
+    if (kt + 1 < nfull) {
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
+      la.store(nxt, tid);
+      lb.store(nxt + K::A_ELEMS, tid);
+      pipelined_step<true, NW, 0>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
+      fold();
+      ++kt;
+    }
+    {
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      pipelined_step<false, 0, 0>(cur, cur + K::A_ELEMS, cur, cur + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
+      fold();
+    }
+  }
+
   // ---- simple path (edge tiles, unaligned operands): element loads, one
   // barrier per K step, loads of the next tile issued before the compute.
   __device__ inline void run_edge(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
@@ -594,6 +671,70 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
           }
           *p = out;
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------ chunked-accumulation GEMM
+// C <- the result of k / BK successive GEMM calls, chunk q being
+//     C <- alpha * op(A)[:, chunk q] * op(B)[chunk q, :] + beta_q * C,
+// beta_0 = g.beta (C is not read when g.beta_zero) and beta_q = 1 afterwards, with C
+// held in registers between the chunks.  Multiplying by one is exact, so beta is applied once, when C is read.
+// The triangular solver uses it to apply the updates of many 16-wide diagonal blocks
+// to a panel in one launch with the rounding of the reference's block-by-block GEMM
+// sequence (src/interface/trsm_interface.hpp:227-380).  The host checks k % BK == 0,
+// k >= BK, 16-byte alignment of both operands and that no vector straddles an edge.
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool REVERSE, int OCC>
+__global__ void __launch_bounds__(WM* WN * 64, OCC)
+    gemm_chunked_kernel(const GemmArgs<T> g) {
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
+  using M = Mfma<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SBAMD_LDS T* smem = (SBAMD_LDS T*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM;
+  const int wn = wave / WM;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  tile_coords(logical, g.tiles_m, g.tiles_n, tm, tn);
+  const int64_t m0 = int64_t(tm) * BM;
+  const int64_t n0 = int64_t(tn) * BN;
+  const int frag_mn = M::lane_mn(lane);
+  const int a_mn = wm * K::WTM + frag_mn;
+  const int b_mn = wn * K::WTN + frag_mn;
+
+  GemmBody<T, BM, BN, BK, WM, WN, TA, TB> body;
+  typename M::acc_t run[K::MI][K::NI];
+  const T beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < K::MI; ++i) {
+    const int64_t mm = m0 + a_mn + i * M::T;
+#pragma unroll
+    for (int j = 0; j < K::NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int64_t nn = n0 + wn * K::WTN + j * M::T + M::acc_i(r, lane);
+        body.acc[i][j][r] = T(0);
+        run[i][j][r] = (!g.beta_zero && mm < g.m && nn < g.n) ? beta * g.c[mm + nn * g.ldc] : T(0);
+      }
+    }
+  }
+
+  body.template run_chunked<REVERSE>(g, g.a, g.b, m0, n0, smem, tid, a_mn, b_mn, run);
+
+#pragma unroll
+  for (int i = 0; i < K::MI; ++i) {
+    const int64_t mm = m0 + a_mn + i * M::T;
+#pragma unroll
+    for (int j = 0; j < K::NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int64_t nn = n0 + wn * K::WTN + j * M::T + M::acc_i(r, lane);
+        if (mm < g.m && nn < g.n) g.c[mm + nn * g.ldc] = run[i][j][r];
       }
     }
   }

@@ -338,6 +338,14 @@ int sbamd_last_splitk(sbamd_handle_t h, int64_t* depth, int64_t* k_chunk) {
   return SBAMD_OK;
 }
 
+int sbamd_last_trsm_launches(sbamd_handle_t h, int64_t* diag, int64_t* panel) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!diag || !panel) return SBAMD_INVALID_VALUE;
+  *diag = h->impl.last_trsm_diag;
+  *panel = h->impl.last_trsm_panel;
+  return SBAMD_OK;
+}
+
 int sbamd_event_record(sbamd_handle_t h, sbamd_event_t* out) {
   if (!h) return SBAMD_INVALID_HANDLE;
   if (!out) return SBAMD_INVALID_VALUE;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 
@@ -22,6 +23,8 @@ struct Handle {
   int last_kernel = -1;
   int64_t last_depth = 1;    // split-K cut of the last call
   int64_t last_k_chunk = 0;
+  int64_t last_trsm_diag = 0;   // how the last _trsm call was carried out
+  int64_t last_trsm_panel = 0;
   // Scratch for the split-K cube (the reference draws it from
   // Temp_Mem_Pool / acquire_temp_mem, src/sb_handle/portblas_handle.hpp:42-101).
   // Grown on demand, reused across calls, freed with the handle.  Work on one
@@ -35,6 +38,26 @@ struct Handle {
   size_t aux_bytes = 0;
   std::mutex mu;
   std::string last_error;
+};
+
+// A kernel attribute (the dynamic LDS limit) belongs to one device's copy of the
+// kernel: remember per kernel which devices have had it set, so a process that
+// holds handles on several GPUs sets it on each.
+struct PerDeviceOnce {
+  std::atomic<uint64_t> done{0};  // bit d: set on device d
+  template <typename F>
+  hipError_t run(F&& set_attribute) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 64) return set_attribute();
+    const uint64_t bit = uint64_t(1) << dev;
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = set_attribute();
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+  }
 };
 
 }  // namespace sbamd

@@ -215,6 +215,12 @@ class SB_Handle:
         _check(self, _lib.load().sbamd_last_splitk(self._h, C.byref(depth), C.byref(chunk)))
         return depth.value, chunk.value
 
+    def last_trsm_launches(self):
+        """(diagonal super-block launches, panel-update launches) of the last _trsm; (0, 0) = block by block."""
+        diag, panel = C.c_int64(), C.c_int64()
+        _check(self, _lib.load().sbamd_last_trsm_launches(self._h, C.byref(diag), C.byref(panel)))
+        return diag.value, panel.value
+
 
 class helper:
     """blas::helper allocation and copy routines (include/portblas_helper.h)."""
