@@ -94,91 +94,159 @@ __global__ void __launch_bounds__(64)
 // W(p, k), the coefficient of X[k] in row p, is A[(o + p) + (o + k) * lda], or with WT the
 // transposed access A[(o + k) + (o + p) * lda]  (WT = trans on the left, !trans on the right);
 // the inverted diagonal blocks are read the same way.
+constexpr int TRSM_DIAG_NT = 512;
+
 template <typename T, bool LEFT, bool WT, bool FORWARD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(TRSM_DIAG_NT)
     trsm_diag_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ inv, const T* __restrict__ B,
                      int64_t ldb, T* __restrict__ X, int64_t ldx, int64_t o, int s, int64_t nq, T alpha,
                      int first_blk) {
-  constexpr int CW = 32, SM = 128, BS = 16;
+  constexpr int CW = 32, SM = 128, BS = 16, NT = TRSM_DIAG_NT;
+  constexpr int RG = NT / CW;  // row groups: a thread owns column q of rows pr, pr + RG, ...
+  using vec_t = typename Mfma<T>::vec_t;
+  constexpr int VL = Mfma<T>::V;
+  constexpr int WSTR = BS + VL;                  // keeps every row 16-byte aligned
+  constexpr int NW = SM * BS / NT;               // coefficient slots one thread stages per block
   __shared__ T V[SM][CW + 1];
   __shared__ T Xi[BS][CW + 1];
   __shared__ T Wi[BS][BS + 1];
-  __shared__ T Ws[SM][BS + 1];
+  __shared__ __attribute__((aligned(16))) T Ws[SM][WSTR];
   const int t = threadIdx.x;
   const int64_t q0 = int64_t(blockIdx.x) * CW;
-  const int total = s * CW;
-  for (int idx = t; idx < total; idx += 256) {
-    const int p = LEFT ? idx % s : idx / CW;  // lanes along the contiguous index
-    const int q = LEFT ? idx / s : idx % CW;
-    T v = T(0);
-    if (q0 + q < nq) v = LEFT ? B[(o + p) + (q0 + q) * ldb] : B[(q0 + q) + (o + p) * ldb];
-    V[p][q] = v;
-  }
-  const int q = t % CW, pr = t / CW;  // 8 row groups
   const int nblk = (s + BS - 1) / BS;
-  for (int step = 0; step < nblk; ++step) {
+
+  // The coefficients of a block -- its inverted diagonal block and the rows of op(A) that
+  // couple it to the blocks still to come -- are fetched into registers one block ahead
+  // and dropped into LDS at the top of the block's step.
+  T winv = T(0), wreg[NW];
+  auto geometry = [&](int step, int& pb, int& cb, int& rem0, int& rem1) {
     const int b = FORWARD ? step : nblk - 1 - step;
-    const int pb = b * BS;
-    const int cb = s - pb < BS ? s - pb : BS;
-    const int rem0 = FORWARD ? pb + BS : 0;  // rows still to come
-    const int rem1 = FORWARD ? s : pb;
-    {
-      const T* blk = inv + (o / BS + b) * (BS * BS);  // column-major: blk[r + c * 16]
-      const int r = t % BS, c = t / BS;
-      if (WT) Wi[c][r] = blk[t];
-      else Wi[r][c] = blk[t];
-      const int nrem = rem1 - rem0;
-      if (nrem > 0) {
-        if (WT) {
-          for (int idx = t; idx < nrem * BS; idx += 256) {
-            const int k = idx % BS, p = rem0 + idx / BS;
-            if (k < cb) Ws[p][k] = A[(o + pb + k) + (o + p) * lda];
-          }
-        } else {
-          for (int idx = t; idx < nrem * cb; idx += 256) {
-            const int p = rem0 + idx % nrem, k = idx / nrem;
-            Ws[p][k] = A[(o + p) + (o + pb + k) * lda];
-          }
-        }
-      }
+    pb = b * BS;
+    cb = s - pb < BS ? s - pb : BS;
+    rem0 = FORWARD ? pb + BS : 0;  // rows still to come
+    rem1 = FORWARD ? (pb + BS < s ? s : pb + BS) : pb;
+  };
+  auto fetch = [&](int step) {
+    int pb, cb, rem0, rem1;
+    geometry(step, pb, cb, rem0, rem1);
+    if (t < BS * BS) winv = inv[(o / BS + pb / BS) * (BS * BS) + t];  // column-major block: [r + c * 16]
+    // slot idx <-> (row p of the super-block, k): fixed, so no division by a run-time count;
+    // rows outside [rem0, rem1) are simply skipped
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = t + i * NT;
+      const int k = WT ? idx % BS : idx / SM;
+      const int p = WT ? idx / BS : idx % SM;
+      const bool live = p >= rem0 && p < rem1 && k < cb;
+      T v = T(0);
+      if (live) v = WT ? A[(o + pb + k) + (o + p) * lda] : A[(o + p) + (o + pb + k) * lda];
+      wreg[i] = v;
     }
+  };
+  auto deposit = [&](int step) {
+    int pb, cb, rem0, rem1;
+    geometry(step, pb, cb, rem0, rem1);
+    const int r = t % BS, c = t / BS;
+    if (t < BS * BS) {
+      if (WT) Wi[c][r] = winv;
+      else Wi[r][c] = winv;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = t + i * NT;
+      const int k = WT ? idx % BS : idx / SM;
+      const int p = WT ? idx / BS : idx % SM;
+      if (p >= rem0 && p < rem1) Ws[p][k] = wreg[i];
+    }
+  };
+
+  fetch(0);
+#pragma unroll 4
+  for (int idx = t; idx < SM * CW; idx += NT) {
+    const int p = LEFT ? idx % SM : idx / CW;  // lanes along the contiguous index
+    const int q = LEFT ? idx / SM : idx % CW;
+    if (p < s) {
+      T v = T(0);
+      if (q0 + q < nq) v = LEFT ? B[(o + p) + (q0 + q) * ldb] : B[(q0 + q) + (o + p) * ldb];
+      V[p][q] = v;
+    }
+  }
+  const int q = t % CW, pr = t / CW;
+  for (int step = 0; step < nblk; ++step) {
+    int pb, cb, rem0, rem1;
+    geometry(step, pb, cb, rem0, rem1);
+    const bool is_first = (pb / BS) == first_blk;
+    deposit(step);
+    if (step + 1 < nblk) fetch(step + 1);
     __syncthreads();
-    for (int pp = pr; pp < cb; pp += 8) {
+    if (cb == BS) {  // one X element per thread; all operands fetched before the chain starts
+      T wi[BS], vk[BS];
+#pragma unroll
+      for (int k = 0; k < BS; ++k) {
+        wi[k] = Wi[pr][k];
+        vk[k] = V[pb + k][q];
+      }
       T acc = T(0);
-      for (int k = 0; k < cb; ++k) acc = fma_rn(Wi[pp][k], V[pb + k][q], acc);
-      Xi[pp][q] = (b == first_blk) ? alpha * acc : acc;
+#pragma unroll
+      for (int k = 0; k < BS; ++k) acc = fma_rn(wi[k], vk[k], acc);
+      Xi[pr][q] = is_first ? alpha * acc : acc;
+    } else if (pr < cb) {
+      T acc = T(0);
+      for (int k = 0; k < cb; ++k) acc = fma_rn(Wi[pr][k], V[pb + k][q], acc);
+      Xi[pr][q] = is_first ? alpha * acc : acc;
     }
     __syncthreads();
     T xk[BS];
 #pragma unroll
     for (int k = 0; k < BS; ++k) xk[k] = k < cb ? Xi[k][q] : T(0);
-    for (int pp = pr; pp < cb; pp += 8) V[pb + pp][q] = Xi[pp][q];
+    if (pr < cb) V[pb + pr][q] = Xi[pr][q];
     if (cb == BS) {
-      for (int p = rem0 + pr; p < rem1; p += 8) {
-        T acc = T(0);
+      // two rows per trip, so the LDS reads of one hide behind the chain of the other
+      for (int p = rem0 + pr; p < rem1; p += 2 * RG) {
+        const int p2 = p + RG < rem1 ? p + RG : p;
+        T w[2][BS];
 #pragma unroll
-        for (int k = 0; k < BS; ++k) acc = fma_rn(Ws[p][k], xk[k], acc);
-        T bc = V[p][q];
-        if (b == first_blk) bc = alpha * bc;
-        const T neg = T(-1) * acc;
-        V[p][q] = neg + bc;
+        for (int g = 0; g < BS / VL; ++g) {
+          const vec_t w0 = *reinterpret_cast<const vec_t*>(&Ws[p][g * VL]);
+          const vec_t w1 = *reinterpret_cast<const vec_t*>(&Ws[p2][g * VL]);
+#pragma unroll
+          for (int e = 0; e < VL; ++e) {
+            w[0][g * VL + e] = w0[e];
+            w[1][g * VL + e] = w1[e];
+          }
+        }
+        T bc0 = V[p][q], bc1 = V[p2][q];
+        T acc0 = T(0), acc1 = T(0);
+#pragma unroll
+        for (int k = 0; k < BS; ++k) {
+          acc0 = fma_rn(w[0][k], xk[k], acc0);
+          acc1 = fma_rn(w[1][k], xk[k], acc1);
+        }
+        if (is_first) {
+          bc0 = alpha * bc0;
+          bc1 = alpha * bc1;
+        }
+        const T neg0 = T(-1) * acc0, neg1 = T(-1) * acc1;
+        V[p][q] = neg0 + bc0;
+        if (p2 != p) V[p2][q] = neg1 + bc1;
       }
     } else {
-      for (int p = rem0 + pr; p < rem1; p += 8) {
+      for (int p = rem0 + pr; p < rem1; p += RG) {
         T acc = T(0);
         for (int k = 0; k < cb; ++k) acc = fma_rn(Ws[p][k], Xi[k][q], acc);
         T bc = V[p][q];
-        if (b == first_blk) bc = alpha * bc;
+        if (is_first) bc = alpha * bc;
         const T neg = T(-1) * acc;
         V[p][q] = neg + bc;
       }
     }
     __syncthreads();
   }
-  for (int idx = t; idx < total; idx += 256) {
-    const int p = LEFT ? idx % s : idx / CW;
-    const int qq = LEFT ? idx / s : idx % CW;
-    if (q0 + qq < nq) {
+#pragma unroll 4
+  for (int idx = t; idx < SM * CW; idx += NT) {
+    const int p = LEFT ? idx % SM : idx / CW;
+    const int qq = LEFT ? idx / SM : idx % CW;
+    if (p < s && q0 + qq < nq) {
       if (LEFT) X[(o + p) + (q0 + qq) * ldx] = V[p][qq];
       else X[(q0 + qq) + (o + p) * ldx] = V[p][qq];
     }
@@ -205,10 +273,10 @@ struct Api<double> {
 // ---- chunked-accumulation GEMM launch (see gemm_chunked_kernel) ----------------
 constexpr int TRSM_BS = 16;  // the reference's diagonal block (trsm_interface.hpp:169)
 
-template <typename T, int BM, int BN, int OCC, bool TA, bool TB, bool REVERSE>
+template <typename T, int BM, int BN, int BK, int WN, int OCC, bool TA, bool TB, bool REVERSE>
 hipError_t launch_chunked_one(GemmArgs<T> g, hipStream_t stream) {
-  using K = GemmTile<T, BM, BN, TRSM_BS, 2, 2, TA, TB>;
-  auto kernel = gemm_chunked_kernel<T, BM, BN, TRSM_BS, 2, 2, TA, TB, REVERSE, OCC>;
+  using K = GemmTile<T, BM, BN, BK, 2, WN, TA, TB>;
+  auto kernel = gemm_chunked_kernel<T, BM, BN, BK, TRSM_BS, 2, WN, TA, TB, REVERSE, OCC>;
   static PerDeviceOnce lds_limit;
   hipError_t e = lds_limit.run([&] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -223,18 +291,18 @@ hipError_t launch_chunked_one(GemmArgs<T> g, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int OCC>
+template <typename T, int BM, int BN, int BK, int WN, int OCC>
 hipError_t launch_chunked_tile(const GemmArgs<T>& g, bool ta, bool tb, bool reverse, hipStream_t stream) {
   // the solver multiplies op(A) * X or X * op(A): at most one operand is transposed
   if (ta && tb) return hipErrorInvalidValue;
   if (reverse) {
-    if (ta) return launch_chunked_one<T, BM, BN, OCC, true, false, true>(g, stream);
-    if (tb) return launch_chunked_one<T, BM, BN, OCC, false, true, true>(g, stream);
-    return launch_chunked_one<T, BM, BN, OCC, false, false, true>(g, stream);
+    if (ta) return launch_chunked_one<T, BM, BN, BK, WN, OCC, true, false, true>(g, stream);
+    if (tb) return launch_chunked_one<T, BM, BN, BK, WN, OCC, false, true, true>(g, stream);
+    return launch_chunked_one<T, BM, BN, BK, WN, OCC, false, false, true>(g, stream);
   }
-  if (ta) return launch_chunked_one<T, BM, BN, OCC, true, false, false>(g, stream);
-  if (tb) return launch_chunked_one<T, BM, BN, OCC, false, true, false>(g, stream);
-  return launch_chunked_one<T, BM, BN, OCC, false, false, false>(g, stream);
+  if (ta) return launch_chunked_one<T, BM, BN, BK, WN, OCC, true, false, false>(g, stream);
+  if (tb) return launch_chunked_one<T, BM, BN, BK, WN, OCC, false, true, false>(g, stream);
+  return launch_chunked_one<T, BM, BN, BK, WN, OCC, false, false, false>(g, stream);
 }
 
 // C <- the k / 16 successive updates  C <- alpha * op(A)[:, q] * op(B)[q, :] + beta_q * C  (beta_0 = beta,
@@ -259,10 +327,17 @@ hipError_t launch_chunked(Handle* h, bool ta, bool tb, bool reverse, int64_t m, 
   g.alpha = alpha;
   g.beta = beta;
   g.beta_zero = (beta == T(0)) ? 1 : 0;
+  // The 128 x 128 tile needs about two workgroups per compute unit to pay off; below that
+  // the 64 x 64 tile spreads the panel over the whole chip.  Its K step holds two chunks
+  // when k allows (k is 16 times a power of two here), which halves the chain of dependent
+  // global loads a workgroup walks through.
+  // (fp32: four waves of 64 x 64; fp64: eight waves of 64 x 32, so that accumulators and running tile
+  // leave room for two waves per SIMD.)
   const int64_t tiles128 = ((m + 127) / 128) * ((n + 127) / 128);
-  if (tiles128 * 2 >= h->compute_units)
-    return launch_chunked_tile<T, 128, 128, sizeof(T) == 4 ? 2 : 1>(g, ta, tb, reverse, h->stream);
-  return launch_chunked_tile<T, 64, 64, 2>(g, ta, tb, reverse, h->stream);
+  if (tiles128 >= 2 * int64_t(h->compute_units))
+    return launch_chunked_tile<T, 128, 128, 16, sizeof(T) == 4 ? 2 : 4, 2>(g, ta, tb, reverse, h->stream);
+  if (k % 32 == 0) return launch_chunked_tile<T, 64, 64, 32, 2, 2>(g, ta, tb, reverse, h->stream);
+  return launch_chunked_tile<T, 64, 64, 16, 2, 2>(g, ta, tb, reverse, h->stream);
 }
 
 int hip_fail(Handle* h, hipError_t e, const char* what) {
@@ -345,7 +420,7 @@ struct TrsmSweep {
     const bool wt = left ? tr : !tr;
     const int s = int(hi - lo);
 #define SBAMD_DIAG(L, W, F)                                                                                       \
-  hipLaunchKernelGGL((trsm_diag_kernel<T, L, W, F>), dim3(grid), dim3(256), 0, h->stream, A, lda, invA, B, ldb, X, \
+  hipLaunchKernelGGL((trsm_diag_kernel<T, L, W, F>), dim3(grid), dim3(TRSM_DIAG_NT), 0, h->stream, A, lda, invA, B, ldb, X, \
                      ldx, lo, s, nq, alpha, fb)
     if (left) {
       if (wt) { if (forward) SBAMD_DIAG(true, true, true); else SBAMD_DIAG(true, true, false); }

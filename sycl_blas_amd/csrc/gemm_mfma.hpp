@@ -487,19 +487,60 @@ struct GemmBody {
     }
   }
 
-  // ---- chunked accumulation: every K step (BK = one chunk) is its own product,
-  // folded into the running tile before the next one starts:
+  // ---- chunked accumulation: every CHUNK of k is its own product, folded into the
+  // running tile before the next one starts:
   //     run <- alpha * (A_chunk * B_chunk) + run        (product and sum rounded apart)
   // which is, element for element and rounding for rounding, what a sequence of
-  // k / BK separate GEMM calls with beta = 1 on the same C computes -- in one pass
-  // over C instead of k / BK passes.  REVERSE walks the chunks from the high end of
-  // K down (k inside a chunk still ascends).  Needs k % BK == 0, k >= BK and
-  // operands the vector path can load.
-  template <bool REVERSE>
+  // k / CHUNK separate GEMM calls with beta = 1 on the same C computes -- in one pass
+  // over C instead of k / CHUNK passes.  A K step of the pipeline holds BK / CHUNK
+  // chunks.  REVERSE walks the chunks from the high end of K down (k inside a chunk
+  // still ascends).  Needs k % BK == 0, k >= BK and operands the vector path can load.
+  //
+  // One K step: the pipelined step above with the fragment groups visited chunk by
+  // chunk (REVERSE: last chunk of the tile first) and a fold behind each chunk.
+  template <bool HAS_NEXT, int NWRITE, int NVMEM, bool REVERSE, int GPC, typename Fold>
+  __device__ inline void chunked_step(const SBAMD_LDS T* as, const SBAMD_LDS T* bs, const SBAMD_LDS T* nas,
+                                      const SBAMD_LDS T* nbs, int a_mn, int b_mn, int lane, frag_a_t& fa,
+                                      frag_b_t& fb, Fold&& fold) {
+    static_assert(K::NGRP % 2 == 0 && K::NGRP % GPC == 0, "whole chunks, fragment double buffer back at slot 0");
+    constexpr int NM = K::MI * K::NI * M::GS;
+#pragma unroll
+    for (int i = 0; i + 1 < K::NGRP; ++i) {
+      fetch_group(as, bs, chunk_order<REVERSE, GPC>(i + 1), a_mn, b_mn, lane, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+      mma_group(fa[i & 1], fb[i & 1]);
+      if ((i + 1) % GPC == 0) fold();
+    }
+    constexpr int SLOTS = K::MI + K::NI;
+    constexpr int STRIDE = NM / SLOTS > 0 ? NM / SLOTS : 1;
+    constexpr int PER = SLOTS / NM > 0 ? SLOTS / NM : 1;
+    if (K::NGRP == GPC) {  // no fold inside the region: the pinned interleave of the plain step
+#pragma unroll
+      for (int n = 0; n < (K::NGRP - 1) * NM; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (n < NWRITE) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        else if (n < NWRITE + NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (n % STRIDE == 0) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+      }
+    }
+    __syncthreads();
+    if (HAS_NEXT) fetch_group(nas, nbs, chunk_order<REVERSE, GPC>(0), a_mn, b_mn, lane, fa[0], fb[0]);
+    mma_group(fa[(K::NGRP - 1) & 1], fb[(K::NGRP - 1) & 1]);
+    fold();
+  }
+
+  // Position i in the visiting order -> fragment group of the tile.
+  template <bool REVERSE, int GPC>
+  __device__ static constexpr int chunk_order(int i) {
+    return REVERSE ? (K::NGRP / GPC - 1 - i / GPC) * GPC + i % GPC : i;
+  }
+
+  template <bool REVERSE, int CHUNK>
   __device__ inline void run_chunked(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
                                      SBAMD_LDS T* smem, int tid, int a_mn, int b_mn,
                                      typename M::acc_t (&run)[K::MI][K::NI]) {
     constexpr int DIR = REVERSE ? -1 : 1;
+    constexpr int GPC = CHUNK / (M::TK * M::GS);  // fragment groups per chunk
+    static_assert(BK % CHUNK == 0 && CHUNK % (M::TK * M::GS) == 0, "a K step holds whole chunks");
     const int lane = tid & 63;
     const int nfull = int(g.k / BK);
     constexpr int NW = LoadA::NWRITE + LoadB::NWRITE;
@@ -534,7 +575,7 @@ struct GemmBody {
     __syncthreads();
     frag_a_t fa;
     frag_b_t fb;
-    fetch_group(buf0, buf0 + K::A_ELEMS, 0, a_mn, b_mn, lane, fa[0], fb[0]);
+    fetch_group(buf0, buf0 + K::A_ELEMS, chunk_order<REVERSE, GPC>(0), a_mn, b_mn, lane, fa[0], fb[0]);
 
     int kt = 0;
     for (; kt + 2 < nfull; ++kt) {
@@ -544,22 +585,22 @@ struct GemmBody {
       lb.store(nxt + K::A_ELEMS, tid);
       la.template load_fast<DIR>(g.lda);
       lb.template load_fast<DIR>(g.ldb);
-      pipelined_step<true, NW, NL>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
-      fold();
+      chunked_step<true, NW, NL, REVERSE, GPC>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb,
+                                               fold);
     }
     if (kt + 1 < nfull) {
       SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
       SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
       la.store(nxt, tid);
       lb.store(nxt + K::A_ELEMS, tid);
-      pipelined_step<true, NW, 0>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
-      fold();
+      chunked_step<true, NW, 0, REVERSE, GPC>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb,
+                                              fold);
       ++kt;
     }
     {
       SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
-      pipelined_step<false, 0, 0>(cur, cur + K::A_ELEMS, cur, cur + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
-      fold();
+      chunked_step<false, 0, 0, REVERSE, GPC>(cur, cur + K::A_ELEMS, cur, cur + K::A_ELEMS, a_mn, b_mn, lane, fa, fb,
+                                              fold);
     }
   }
 
@@ -677,15 +718,15 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 }
 
 // ------------------------------------------------ chunked-accumulation GEMM
-// C <- the result of k / BK successive GEMM calls, chunk q being
+// C <- the result of k / CHUNK successive GEMM calls, chunk q being
 //     C <- alpha * op(A)[:, chunk q] * op(B)[chunk q, :] + beta_q * C,
 // beta_0 = g.beta (C is not read when g.beta_zero) and beta_q = 1 afterwards, with C
 // held in registers between the chunks.  Multiplying by one is exact, so beta is applied once, when C is read.
 // The triangular solver uses it to apply the updates of many 16-wide diagonal blocks
 // to a panel in one launch with the rounding of the reference's block-by-block GEMM
 // sequence (src/interface/trsm_interface.hpp:227-380).  The host checks k % BK == 0,
-// k >= BK, 16-byte alignment of both operands and that no vector straddles an edge.
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool REVERSE, int OCC>
+// k >= BK (BK = the K step of the pipeline, a multiple of CHUNK), 16-byte alignment of both operands and that no vector straddles an edge.
+template <typename T, int BM, int BN, int BK, int CHUNK, int WM, int WN, bool TA, bool TB, bool REVERSE, int OCC>
 __global__ void __launch_bounds__(WM* WN * 64, OCC)
     gemm_chunked_kernel(const GemmArgs<T> g) {
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
@@ -724,7 +765,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     }
   }
 
-  body.template run_chunked<REVERSE>(g, g.a, g.b, m0, n0, smem, tid, a_mn, b_mn, run);
+  body.template run_chunked<REVERSE, CHUNK>(g, g.a, g.b, m0, n0, smem, tid, a_mn, b_mn, run);
 
 #pragma unroll
   for (int i = 0; i < K::MI; ++i) {
