@@ -305,11 +305,12 @@ hipError_t launch_chunked_tile(const GemmArgs<T>& g, bool ta, bool tb, bool reve
   return launch_chunked_one<T, BM, BN, BK, WN, OCC, false, false, false>(g, stream);
 }
 
-// C <- the k / 16 successive updates  C <- alpha * op(A)[:, q] * op(B)[q, :] + beta_q * C  (beta_0 = beta,
+// C <- the k / 16 successive updates  C <- -1 * op(A)[:, q] * op(B)[q, :] + beta_q * C  (beta_0 = beta,
 // then 1), chunks ascending or, with `reverse`, descending.  The caller has checked the operands.
 template <typename T>
 hipError_t launch_chunked(Handle* h, bool ta, bool tb, bool reverse, int64_t m, int64_t n, int64_t k, T alpha,
                           const T* a, int64_t lda, const T* b, int64_t ldb, T beta, T* c, int64_t ldc) {
+  if (!(alpha == T(-1))) return hipErrorInvalidValue;  // the kernel subtracts
   GemmArgs<T> g{};
   g.a = a;
   g.b = b;

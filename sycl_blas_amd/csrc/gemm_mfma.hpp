@@ -489,9 +489,9 @@ struct GemmBody {
 
   // ---- chunked accumulation: every CHUNK of k is its own product, folded into the
   // running tile before the next one starts:
-  //     run <- alpha * (A_chunk * B_chunk) + run        (product and sum rounded apart)
+  //     run <- -(A_chunk * B_chunk) + run        (product and sum rounded apart)
   // which is, element for element and rounding for rounding, what a sequence of
-  // k / CHUNK separate GEMM calls with beta = 1 on the same C computes -- in one pass
+  // k / CHUNK separate GEMM calls with alpha = -1, beta = 1 on the same C computes -- in one pass
   // over C instead of k / CHUNK passes.  A K step of the pipeline holds BK / CHUNK
   // chunks.  REVERSE walks the chunks from the high end of K down (k inside a chunk
   // still ascends).  Needs k % BK == 0, k >= BK and operands the vector path can load.
@@ -547,7 +547,7 @@ struct GemmBody {
     constexpr int NL = LoadA::NV + LoadB::NV;
     SBAMD_LDS T* const buf0 = smem;
     SBAMD_LDS T* const buf1 = smem + K::STAGE_ELEMS;
-    const T alpha = g.alpha;
+    // alpha is -1 here (checked on the host): (-1 * acc) + run is run - acc, bit for bit.
     auto fold = [&]() {
 #pragma unroll
       for (int i = 0; i < K::MI; ++i)
@@ -555,8 +555,7 @@ struct GemmBody {
         for (int j = 0; j < K::NI; ++j)
 #pragma unroll
           for (int r = 0; r < M::NACC; ++r) {
-            const T t = alpha * acc[i][j][r];
-            run[i][j][r] = t + run[i][j][r];
+            run[i][j][r] = run[i][j][r] - acc[i][j][r];
             acc[i][j][r] = T(0);
           }
     };
@@ -719,7 +718,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 
 // ------------------------------------------------ chunked-accumulation GEMM
 // C <- the result of k / CHUNK successive GEMM calls, chunk q being
-//     C <- alpha * op(A)[:, chunk q] * op(B)[chunk q, :] + beta_q * C,
+//     C <- -1 * op(A)[:, chunk q] * op(B)[chunk q, :] + beta_q * C,
 // beta_0 = g.beta (C is not read when g.beta_zero) and beta_q = 1 afterwards, with C
 // held in registers between the chunks.  Multiplying by one is exact, so beta is applied once, when C is read.
 // The triangular solver uses it to apply the updates of many 16-wide diagonal blocks
