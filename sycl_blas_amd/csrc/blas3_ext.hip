@@ -287,7 +287,12 @@ hipError_t launch_chunked_one(GemmArgs<T> g, hipStream_t stream) {
   g.tiles_n = int32_t((g.n + BN - 1) / BN);
   const int64_t grid = int64_t(g.tiles_m) * g.tiles_n;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(K::NT), K::LDS_BYTES, stream, g);
+  // 16-byte loads along M / N may run up to the next multiple of a vector on an M/N-major
+  // operand; the caller provides storage up to there.
+  constexpr int64_t V = 16 / sizeof(T);
+  const int64_t m_lim = TA ? g.m : (g.m + V - 1) / V * V;
+  const int64_t n_lim = TB ? (g.n + V - 1) / V * V : g.n;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(K::NT), K::LDS_BYTES, stream, g, m_lim, n_lim);
   return hipGetLastError();
 }
 
@@ -389,8 +394,8 @@ int symm(sbamd_handle_t hh, char side, char uplo, int64_t m, int64_t n, T alpha,
 // folded into the running tile every 16), before the second half is solved.  Every
 // element still receives the same products in the same order with the same roundings, so
 // the result equals the block-by-block sweep bit for bit; the work on B drops from
-// O(K/16) passes to O(log K).  Operands the chunked kernel cannot take (unaligned, or an
-// edge a 16-byte vector would straddle) fall back to the block-by-block sweep.
+// O(K/16) passes to O(log K).  The chunked kernel loads 16-byte vectors: X is laid out for
+// it, and an A it could not read that way is copied once into aligned, padded scratch.
 template <typename T>
 struct TrsmSweep {
   sbamd_handle_t hh;
@@ -405,12 +410,13 @@ struct TrsmSweep {
   T* X;
   int64_t ldx;
   const T* invA;
+  const T* Ap;  // A as the GEMM calls read it: A itself, or its 16-byte-aligned, padded copy
+  int64_t ldap;
 
   static constexpr int64_t bs = TRSM_BS;
   static constexpr int64_t super = 128;  // rows one trsm_diag_kernel launch solves
-  int64_t first = 0;     // the block whose calls carry alpha (-1: already spent)
-  bool chunked = false;  // multi-block updates may use the chunked kernel
-  bool fused = false;    // diagonal super-blocks go to trsm_diag_kernel
+  int64_t first = 0;   // the block whose calls carry alpha (-1: already spent)
+  bool fused = false;  // diagonal super-blocks go to trsm_diag_kernel
   int64_t panel_launches = 0, diag_launches = 0;
 
   // All blocks of [lo, hi) (at most `super` rows) in one launch.
@@ -453,16 +459,16 @@ struct TrsmSweep {
     const T beta = has_first ? alpha : T(1);
     const char tc = tr ? 't' : 'n';
     const int64_t k = s1 - s0;
-    const T* ablk = left ? A + (!tr ? d0 + s0 * lda : s0 + d0 * lda) : A + (!tr ? s0 + d0 * lda : d0 + s0 * lda);
-    if (k <= bs || !chunked) {
-      if (left) return Api<T>::gemm(hh, tc, 'n', d1 - d0, N, k, T(-1), ablk, lda, X + s0, ldx, beta, B + d0, ldb);
-      return Api<T>::gemm(hh, 'n', tc, M, d1 - d0, k, T(-1), X + s0 * ldx, ldx, ablk, lda, beta, B + d0 * ldb, ldb);
+    const T* ablk = left ? Ap + (!tr ? d0 + s0 * ldap : s0 + d0 * ldap) : Ap + (!tr ? s0 + d0 * ldap : d0 + s0 * ldap);
+    if (k <= bs) {
+      if (left) return Api<T>::gemm(hh, tc, 'n', d1 - d0, N, k, T(-1), ablk, ldap, X + s0, ldx, beta, B + d0, ldb);
+      return Api<T>::gemm(hh, 'n', tc, M, d1 - d0, k, T(-1), X + s0 * ldx, ldx, ablk, ldap, beta, B + d0 * ldb, ldb);
     }
     ++panel_launches;
-    hipError_t e = left ? launch_chunked<T>(h, tr, false, !forward, d1 - d0, N, k, T(-1), ablk, lda, X + s0, ldx, beta,
+    hipError_t e = left ? launch_chunked<T>(h, tr, false, !forward, d1 - d0, N, k, T(-1), ablk, ldap, X + s0, ldx, beta,
                                             B + d0, ldb)
-                        : launch_chunked<T>(h, false, tr, !forward, M, d1 - d0, k, T(-1), X + s0 * ldx, ldx, ablk, lda,
-                                            beta, B + d0 * ldb, ldb);
+                        : launch_chunked<T>(h, false, tr, !forward, M, d1 - d0, k, T(-1), X + s0 * ldx, ldx, ablk,
+                                            ldap, beta, B + d0 * ldb, ldb);
     return e == hipSuccess ? SBAMD_OK : hip_fail(h, e, "trsm update launch");
   }
 
@@ -491,45 +497,10 @@ struct TrsmSweep {
   }
 
   int run() {
-    constexpr int V = 16 / sizeof(T);
     const int64_t K = extent();
-    const bool aligned = reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0 &&
-                         lda % V == 0 && ldx % V == 0;
-    // op(A) K-major needs nothing more; an M/N-major operand must not straddle its edge
-    chunked = aligned && (left ? (tr || M % V == 0) : (M % V == 0 && (!tr || N % V == 0)));
     // alpha == 0 turns the first block's GEMM calls into the reference's scaling path
     // (gemm_interface.hpp:112-139): leave that to the GEMM entry point.
     fused = !(alpha == T(0));
-    if (!chunked) {
-      // The reference's sweep: one update call per 16-wide block over everything still to
-      // come; the blocks of a super-block are solved together first when that is allowed
-      // (an element outside the super-block sees the same updates in the same order).
-      const int64_t group = fused ? super : bs;
-      if (forward) {
-        first = 0;
-        for (int64_t lo = 0; lo < K; lo += group) {
-          const int64_t hi = std::min(K, lo + group);
-          int st = solve(lo, hi);
-          if (st != SBAMD_OK) return st;
-          for (int64_t i = lo; i < hi && hi < K; i += bs)
-            if ((st = update(i, i + bs, hi, K)) != SBAMD_OK) return st;
-        }
-      } else {
-        const int64_t special = (K % bs == 0) ? bs : (K % bs);
-        first = K - special;
-        for (int64_t hi = K; hi > 0;) {
-          // whole blocks below the ragged one: group boundaries stay multiples of 16
-          const int64_t lo = hi - group > 0 ? (hi - group + bs - 1) / bs * bs : 0;
-          int st = solve(lo, hi);
-          if (st != SBAMD_OK) return st;
-          if (lo > 0)
-            for (int64_t i = (hi - 1) / bs * bs; i >= lo; i -= bs)
-              if ((st = update(i, std::min(i + bs, hi), 0, lo)) != SBAMD_OK) return st;
-          hi = lo;
-        }
-      }
-      return SBAMD_OK;
-    }
     if (forward) {
       first = 0;
       return solve(0, K);
@@ -570,12 +541,34 @@ int trsm(sbamd_handle_t hh, char side, char uplo, char trans, char diag, int64_t
   constexpr int64_t bs = 16;
   const int64_t nblocks = (K + bs - 1) / bs;
   const int64_t inv_elems = nblocks * bs * bs;
-  const int64_t b_elems = ldb * (N - 1) + M;
+  // X: the M x N window of B in a layout the vector loads can use (columns start 16-byte
+  // aligned, rows exist up to a whole vector).  The reference copies the whole ldb-strided
+  // buffer back and forth (trsm_interface.hpp:199-208, :384-389); the rows between M and ldb
+  // make the round trip unchanged there and are simply left alone here.
+  constexpr int64_t V = 16 / sizeof(T);
+  const int64_t ldx = (M + V - 1) / V * V;
+  const int64_t x_elems = ldx * N;
+  // A copy of A when 16-byte loads cannot read it in place: unaligned, or read along its
+  // columns (M/N-major) with an extent that ends inside a vector.
+  const bool a_mn_major = left ? !tr : tr;
+  const bool a_in_place = reinterpret_cast<uintptr_t>(A) % 16 == 0 && lda % V == 0 && !(a_mn_major && K % V != 0);
+  const int64_t ldac = (K + V - 1) / V * V;
+  const int64_t a_elems = a_in_place ? 0 : ldac * K;
 
-  hipError_t e = ensure_aux(h, size_t(inv_elems + b_elems) * sizeof(T));
+  hipError_t e = ensure_aux(h, size_t(inv_elems + x_elems + a_elems) * sizeof(T));
   if (e != hipSuccess) return hip_fail(h, e, "trsm scratch");
   T* invA = static_cast<T*>(h->aux);
   T* X = invA + inv_elems;
+  const T* Ap = A;
+  int64_t ldap = lda;
+  if (!a_in_place) {
+    T* acopy = X + x_elems;
+    e = hipMemcpy2DAsync(acopy, size_t(ldac) * sizeof(T), A, size_t(lda) * sizeof(T), size_t(K) * sizeof(T), size_t(K),
+                         hipMemcpyDeviceToDevice, h->stream);
+    if (e != hipSuccess) return hip_fail(h, e, "trsm copy of A");
+    Ap = acopy;
+    ldap = ldac;
+  }
   e = hipMemsetAsync(invA, 0, size_t(inv_elems) * sizeof(T), h->stream);
   if (e != hipSuccess) return hip_fail(h, e, "trsm memset");
   const unsigned grid = unsigned((nblocks + 3) / 4);
@@ -585,18 +578,19 @@ int trsm(sbamd_handle_t hh, char side, char uplo, char trans, char diag, int64_t
   if (!unit && !upper) hipLaunchKernelGGL((trsm_invert_blocks_kernel<T, false, false>), dim3(grid), dim3(64), 0, h->stream, A, lda, K, nblocks, invA);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, e, "trsm inverter launch");
-  // X starts as a copy of B (the whole ldb-strided range), trsm_interface.hpp:199-208
-  e = hipMemcpyAsync(X, B, size_t(b_elems) * sizeof(T), hipMemcpyDeviceToDevice, h->stream);
+  // X starts as a copy of B
+  e = hipMemcpy2DAsync(X, size_t(ldx) * sizeof(T), B, size_t(ldb) * sizeof(T), size_t(M) * sizeof(T), size_t(N),
+                       hipMemcpyDeviceToDevice, h->stream);
   if (e != hipSuccess) return hip_fail(h, e, "trsm copy");
-  const int64_t ldx = ldb;
   const bool forward = left ? ((upper && tr) || (!upper && !tr)) : !((upper && tr) || (!upper && !tr));
-  TrsmSweep<T> sw{hh, h, left, tr, forward, M, N, alpha, A, lda, B, ldb, X, ldx, invA};
+  TrsmSweep<T> sw{hh, h, left, tr, forward, M, N, alpha, A, lda, B, ldb, X, ldx, invA, Ap, ldap};
   const int st = sw.run();
   h->last_trsm_diag = sw.diag_launches;
   h->last_trsm_panel = sw.panel_launches;
   if (st != SBAMD_OK) return st;
   // the result travels back into B (:384-389)
-  e = hipMemcpyAsync(B, X, size_t(b_elems) * sizeof(T), hipMemcpyDeviceToDevice, h->stream);
+  e = hipMemcpy2DAsync(B, size_t(ldb) * sizeof(T), X, size_t(ldx) * sizeof(T), size_t(M) * sizeof(T), size_t(N),
+                       hipMemcpyDeviceToDevice, h->stream);
   if (e != hipSuccess) return hip_fail(h, e, "trsm copy back");
   return SBAMD_OK;
 }

@@ -536,7 +536,7 @@ struct GemmBody {
 
   template <bool REVERSE, int CHUNK>
   __device__ inline void run_chunked(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
-                                     SBAMD_LDS T* smem, int tid, int a_mn, int b_mn,
+                                     int64_t m_lim, int64_t n_lim, SBAMD_LDS T* smem, int tid, int a_mn, int b_mn,
                                      typename M::acc_t (&run)[K::MI][K::NI]) {
     constexpr int DIR = REVERSE ? -1 : 1;
     constexpr int GPC = CHUNK / (M::TK * M::GS);  // fragment groups per chunk
@@ -561,8 +561,8 @@ struct GemmBody {
     };
 
     const int64_t k_first = REVERSE ? g.k - BK : 0;
-    la.init_fast(a, g.lda, m0, g.m, k_first, tid);
-    lb.init_fast(b, g.ldb, n0, g.n, k_first, tid);
+    la.init_fast(a, g.lda, m0, m_lim, k_first, tid);
+    lb.init_fast(b, g.ldb, n0, n_lim, k_first, tid);
     la.template load_fast<DIR>(g.lda);
     lb.template load_fast<DIR>(g.ldb);
     la.store(buf0, tid);
@@ -724,10 +724,14 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 // The triangular solver uses it to apply the updates of many 16-wide diagonal blocks
 // to a panel in one launch with the rounding of the reference's block-by-block GEMM
 // sequence (src/interface/trsm_interface.hpp:227-380).  The host checks k % BK == 0,
-// k >= BK (BK = the K step of the pipeline, a multiple of CHUNK), 16-byte alignment of both operands and that no vector straddles an edge.
+// k >= BK (BK = the K step of the pipeline, a multiple of CHUNK) and 16-byte alignment of
+// both operands.  m_lim / n_lim bound the 16-byte loads along M / N: the matrix extent for a
+// K-major operand, the extent rounded up to a whole vector for an M/N-major one -- whose
+// storage must then exist up to there (what a straddling vector picks up only feeds rows or
+// columns that are never stored).
 template <typename T, int BM, int BN, int BK, int CHUNK, int WM, int WN, bool TA, bool TB, bool REVERSE, int OCC>
 __global__ void __launch_bounds__(WM* WN * 64, OCC)
-    gemm_chunked_kernel(const GemmArgs<T> g) {
+    gemm_chunked_kernel(const GemmArgs<T> g, int64_t m_lim, int64_t n_lim) {
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
   using M = Mfma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -764,7 +768,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     }
   }
 
-  body.template run_chunked<REVERSE, CHUNK>(g, g.a, g.b, m0, n0, smem, tid, a_mn, b_mn, run);
+  body.template run_chunked<REVERSE, CHUNK>(g, g.a, g.b, m0, n0, m_lim, n_lim, smem, tid, a_mn, b_mn, run);
 
 #pragma unroll
   for (int i = 0; i < K::MI; ++i) {

@@ -116,9 +116,9 @@ def test_trsm(sb_handle, dtype, side, uplo):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("side", ["l", "r"])
 def test_trsm_routes(sb_handle, dtype, side):
-    """Shapes whose operands are 16-byte aligned take the super-block / panel kernels; odd ones fall back to
-    one update call per 16-wide block (with the super-block solver) -- and alpha == 0 solves block by block.
-    Every route must give the oracle's bits: the oracle is the reference's block-by-block GEMM sequence."""
+    """Aligned, ragged and odd shapes (odd ones make the solver read A through an aligned copy), every sweep
+    direction, and alpha == 0 (whose first block goes through the GEMM entry point's scaling path).  Every
+    route must give the oracle's bits: the oracle is the reference's block-by-block GEMM sequence."""
     seen = set()
     for (m, n), trans, uplo, diag, alpha in [
             ((528, 260), "n", "l", "n", 2.0), ((528, 260), "t", "u", "u", 2.0), ((528, 260), "n", "u", "n", 0.5),
@@ -126,7 +126,8 @@ def test_trsm_routes(sb_handle, dtype, side):
             ((1036, 132), "n", "l", "u", 2.0), ((1036, 132), "t", "l", "n", 2.0), ((1036, 132), "n", "u", "n", 2.0),
             ((132, 1036), "n", "l", "n", 2.0), ((132, 1036), "t", "u", "n", 2.0), ((132, 1036), "n", "u", "u", 2.0),
             ((132, 1036), "t", "l", "n", 2.0),
-            ((301, 515), "n", "l", "n", 2.0), ((301, 515), "t", "u", "n", 2.0),
+            ((301, 515), "n", "l", "n", 2.0), ((301, 515), "t", "u", "n", 2.0), ((515, 301), "n", "u", "n", 2.0),
+            ((515, 301), "t", "l", "u", 2.0),
             ((260, 264), "n", "l", "n", 0.0), ((260, 264), "t", "u", "n", 0.0)]:
         for lda_mul in (1, 2):
             case = (m, n, trans, side, diag, uplo, alpha, lda_mul, 1, float("nan"))
@@ -134,15 +135,12 @@ def test_trsm_routes(sb_handle, dtype, side):
             diag_launches, panel_launches = sb_handle.last_trsm_launches()
             k = m if side == "l" else n
             if alpha == 0.0:
-                assert diag_launches == 0  # the first block's calls are the GEMM entry point's scaling path
+                assert diag_launches == 0 and panel_launches >= 1, case
                 seen.add("blocks")
-            elif m % 4 == 0 and n % 4 == 0:
+            else:
                 assert diag_launches >= 1 and (panel_launches >= 1 or k < 512), case
                 seen.add("panels" if panel_launches else "diag")
-            else:
-                assert diag_launches >= 1
-                seen.add("panels" if panel_launches else "diag+blocks")
-    assert {"blocks", "panels"} <= seen
+    assert {"blocks", "panels", "diag"} <= seen
 
 
 def test_trsm_argument_errors(sb_handle):
