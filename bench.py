@@ -167,6 +167,22 @@ def side_measurements(torch, sb, handle, size):
                                               "pct_mfma_peak": round(100 * tf / PEAK_TFLOPS["bf16"], 2)}
     for buf in (a, b, c):
         helper.deallocate(buf)
+
+    # a caller of the GEMM path: STRSM, left / lower / no transpose / non-unit, size x size.
+    # Off-diagonal entries are scaled so that the solution stays O(1) over thousands of rows.
+    ta_t = torch.rand(size, size, dtype=torch.float32, device="cuda").mul_(1.0 / size)
+    ta_t.diagonal().fill_(2.0)
+    tb_t = torch.rand(size * size, dtype=torch.float32, device="cuda")
+    from sycl_blas_amd import DeviceBuffer
+    a = DeviceBuffer.from_pointer(ta_t.data_ptr(), "float32", size * size, ta_t)
+    b = DeviceBuffer.from_pointer(tb_t.data_ptr(), "float32", size * size, tb_t)
+    torch.cuda.synchronize()
+    ms = device_time_ms(sb, handle, lambda: sb._trsm(handle, "l", "l", "n", "n", size, size, 1.0, a, size, b, size),
+                        3, warm=1)
+    diag_launches, panel_launches = handle.last_trsm_launches()
+    extras[f"strsm_llnn_{size}"] = {"ms": round(ms, 3), "tflops": round(float(size) ** 3 / ms / 1e9, 2),
+                                    "launches": {"diagonal": diag_launches, "panel": panel_launches}}
+    del a, b, ta_t, tb_t
     return extras
 
 
