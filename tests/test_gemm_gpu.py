@@ -158,3 +158,17 @@ def test_cpp_sample_through_compat_header():
         out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "PASS" in out.stdout
+
+
+def test_cpp_symm_trsm_sample_through_compat_header():
+    """samples/symm_trsm.cpp: blas::_symm with the reference sample's arguments (samples/symm.cpp:18-26) and blas::_trsm."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "samples", "symm_trsm_sample")
+    assert os.path.exists(exe), "build it with `make -C samples` (or __graft_entry__.build())"
+    for args in ([], ["600"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "PASS" in out.stdout
