@@ -58,6 +58,13 @@ hipError_t launch_tile(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
             : launch_one<T, BM, BN, BK, WM, WN, OCC, false, false>(g, nz, stream);
 }
 
+// The biggest tile: 256 x 256 (float) / 256 x 128 (double), eight waves as 4 (M) x 2 (N).
+// With both operands transposed the fp32 kernel mirrors the wave grid to 2 x 4: A is then
+// the K-major operand and B the N-major one, and the fragment traffic per wave is that of
+// the untransposed case with the roles of M and N swapped.
+template <typename T>
+hipError_t launch_huge(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream);
+
 template <typename T>
 hipError_t launch_interleaved(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream) {
   constexpr int IR = 4, IC = 4;
@@ -146,6 +153,19 @@ struct CostModel<double> {
   static constexpr CostOverheads over = {4.75, 8.04, 6.02e6, 0.0295};
 };
 
+template <typename T>
+hipError_t launch_huge(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
+  if constexpr (sizeof(T) == 4) {
+    if (ta && tb) {
+      g.tiles_m = int32_t(ceil_div(g.m, 256));
+      g.tiles_n = int32_t(ceil_div(g.n, 256));
+      return launch_one<T, 256, 256, Tiles<T>::HUGE_BK, 2, 4, Tiles<T>::HUGE_OCC, true, true>(
+          g, g.split_k > 1 ? g.split_k : g.batch, stream);
+    }
+  }
+  return launch_tile<T, 256, Tiles<T>::HUGE_BN, Tiles<T>::HUGE_BK, 4, 2, Tiles<T>::HUGE_OCC>(g, ta, tb, stream);
+}
+
 // Estimated microseconds for `tile` with the K range cut into `depth` slabs.
 template <typename T>
 inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t k, int64_t batch, bool ta,
@@ -160,8 +180,6 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
   const int64_t busiest = ceil_div(wgs, cus);  // workgroups the fullest compute unit runs
   const int64_t full = busiest / occ, rem = busiest % occ;
   double us_per_k = double(full) * per_k[occ - 1] + (rem ? per_k[rem - 1] : 0.0);
-  // fp32 with both operands transposed runs the biggest tile slower than the 128x128 one
-  if (tile == TILE_256 && sizeof(T) == 4 && ta && tb) us_per_k *= 1.22;
   const int64_t k_chunk = bk * ceil_div(k, int64_t(bk) * depth);
   double us = us_per_k * double(k_chunk);
   if (depth > 1) {
@@ -325,7 +343,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     gp.k_chunk = k_chunk;
     gp.slice_stride = slice;
     gp.beta_zero = 1;
-    e = plan.tile == TILE_256   ? launch_tile<T, 256, Tiles<T>::HUGE_BN, Tiles<T>::HUGE_BK, 4, 2, Tiles<T>::HUGE_OCC>(gp, p.ta, p.tb, h->stream)
+    e = plan.tile == TILE_256   ? launch_huge<T>(gp, p.ta, p.tb, h->stream)
         : plan.tile == TILE_128 ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream)
                                 : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
     if (e != hipSuccess) return e;
@@ -345,7 +363,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       return launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, 2, 2, 2>(g, p.ta, p.tb, h->stream);
     case TILE_256:
       h->last_kernel = SBAMD_KERNEL_HUGE;
-      return launch_tile<T, 256, Tiles<T>::HUGE_BN, Tiles<T>::HUGE_BK, 4, 2, Tiles<T>::HUGE_OCC>(g, p.ta, p.tb, h->stream);
+      return launch_huge<T>(g, p.ta, p.tb, h->stream);
     default:
       h->last_kernel = SBAMD_KERNEL_SMALL;
       // Short K (the batched 64x64x64 class): stage the whole K range at once --
