@@ -1,4 +1,5 @@
-// Timing-only ablation of the fp32 256x128x32 NN kernel at 8192^3 (see SBAMD_ABLATE in
+// Timing-only ablation of fp32 NN kernels (256x128x32 and 128x128x16 at 8192^3, the small tiles at
+// sizes that give one workgroup per compute unit) (see SBAMD_ABLATE in
 // gemm_mfma.hpp).  Build one binary per mask:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DSBAMD_ABLATE=<mask> \
 //         -Isycl_blas_amd/csrc tools/ablate.hip -o /tmp/ablate_<mask>
@@ -20,7 +21,7 @@ using namespace sbamd;
   } while (0)
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC>
-int run(const char* name, int n) {
+int run(const char* name, int n, int reps = 5) {
   using K = GemmTile<T, BM, BN, BK, WM, WN, false, false>;
   T *a, *b, *c;
   CHECK(hipMalloc(&a, sizeof(T) * n * n));
@@ -44,7 +45,6 @@ int run(const char* name, int n) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  const int reps = 5;
   for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kernel, dim3(g.tiles_m * g.tiles_n), dim3(K::NT), K::LDS_BYTES, 0, g);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
@@ -60,7 +60,13 @@ int run(const char* name, int n) {
 }
 
 int main() {
+  if (run<float, 256, 256, 16, 4, 2, 2>("f32 256x256x16", 8192)) return 1;
+  if (run<float, 256, 256, 16, 4, 4, 4>("f32 256x256x16 (16 waves)", 8192)) return 1;
+  if (run<float, 256, 256, 32, 4, 4, 4>("f32 256x256x32 (16 waves)", 8192)) return 1;
   if (run<float, 256, 128, 32, 4, 2, 1>("f32 256x128x32", 8192)) return 1;
   if (run<float, 128, 128, 16, 2, 2, 2>("f32 128x128x16", 8192)) return 1;
+  // one workgroup per compute unit: where does a K step go when nothing else runs beside it?
+  if (run<float, 64, 64, 32, 2, 2, 4>("f32 64x64x32", 1024, 200)) return 1;
+  if (run<float, 128, 128, 32, 4, 2, 2>("f32 128x128x32 (8 waves)", 2048, 50)) return 1;
   return 0;
 }
