@@ -94,6 +94,10 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
           cands.push_back({std::string("splitk ") + tile_names[tile] + " depth " + std::to_string(depth),
                            SBAMD_KERNEL_SPLITK, depth | (tile << 16), false});
         }
+      // both halves of K in one workgroup (falls back to the cube route when K does not split into whole K steps)
+      for (int tile = 1; tile <= 2; ++tile)
+        cands.push_back({std::string("halves ") + tile_names[tile] + " (two K halves per workgroup)", SBAMD_KERNEL_SPLITK,
+                         2 | (tile << 16) | (1 << 24), false});
     }
     if (double(m) * double(n) * double(k) * double(bs) <= 8e9)  // the scalar kernel is for checking, keep it short
       cands.push_back({"naive  one element per lane", SBAMD_KERNEL_NAIVE, 0, true});

@@ -100,7 +100,9 @@ const char* sbamd_last_error(sbamd_handle_t h);
 /* Pin a kernel family (SBAMD_KERNEL_*); `param` is family specific.
  * Split-K: bits 0-15 = cube depth (0 = derive from the compute-unit count as
  * src/operations/blas3/gemm_partial_local.hpp:191-199 does), bits 16-23 = tile of
- * the partial products (0 = automatic, 1 = 64x64, 2 = 128x128, 3 = the biggest tile). */
+ * the partial products (0 = automatic, 1 = 64x64, 2 = 128x128, 3 = the biggest tile), bit 24 = keep
+ * both halves of K (depth 2) inside one workgroup of the 64x64 / 128x128 tile instead of going through
+ * the cube (same result as the cube route with two slabs; needs K to split into whole K steps). */
 int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param);
 
 /* Which family the last GEMM call on this handle launched (SBAMD_KERNEL_*),

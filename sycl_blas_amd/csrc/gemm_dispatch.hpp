@@ -58,6 +58,37 @@ hipError_t launch_tile(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
             : launch_one<T, BM, BN, BK, WM, WN, OCC, false, false>(g, nz, stream);
 }
 
+// Both halves of K in one workgroup (gemm_mfma_halves_kernel); g.k_chunk = k / 2.
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB>
+hipError_t launch_halves_one(const GemmArgs<T>& g, hipStream_t stream) {
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
+  auto kernel = gemm_mfma_halves_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC>;
+  constexpr size_t lds = 2 * K::LDS_BYTES;
+  static_assert(lds <= 160 * 1024, "two sets of buffers must fit the LDS");
+  static PerDeviceOnce lds_limit;
+  hipError_t e = lds_limit.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(lds));
+  });
+  if (e != hipSuccess) return e;
+  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * g.batch;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(2 * K::NT), lds, stream, g);
+  return hipGetLastError();
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC>
+hipError_t launch_halves(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
+  g.tiles_m = int32_t(ceil_div(g.m, BM));
+  g.tiles_n = int32_t(ceil_div(g.n, BN));
+  if (ta) {
+    return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, true>(g, stream)
+              : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, false>(g, stream);
+  }
+  return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, true>(g, stream)
+            : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, false>(g, stream);
+}
+
 // The biggest tile: 256 x 256 (float) / 256 x 128 (double), eight waves as 4 (M) x 2 (N).
 // With both operands transposed the fp32 kernel mirrors the wave grid to 2 x 4: A is then
 // the K-major operand and B the N-major one, and the fragment traffic per wave is that of
@@ -122,6 +153,7 @@ enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5 };
 struct Plan {
   int tile;
   int64_t depth;
+  bool fused = false;  // depth == 2 with both halves of K inside one workgroup (no cube)
 };
 
 // Cost model of one launch, fitted to a sweep of every (tile, depth) pair over
@@ -145,6 +177,9 @@ struct CostModel<float> {
   static constexpr double small_k[4] = {0.0237, 0.0398, 0.0584, 0.0707};
   static constexpr double large_k[2] = {0.0680, 0.1245};  // the fit x 0.964: the eight-wave layout came after the sweep
   static constexpr double huge_k[1] = {0.2463};  // 256 x 256 tile
+  // two K halves in one workgroup, relative to two resident workgroups of the tile {64x64, 128x128}
+  // (1024^3: 26.6 us, 2048^3: 138 us measured)
+  static constexpr double halves_factor[2] = {1.13, 1.055};
   static constexpr CostOverheads over = {3.53, 7.30, 4.92e6, 0.0498};
 };
 template <>
@@ -152,6 +187,7 @@ struct CostModel<double> {
   static constexpr double small_k[4] = {0.0460, 0.0804, 0.1138, 0.1415};
   static constexpr double large_k[2] = {0.1191, 0.2375};
   static constexpr double huge_k[1] = {0.2323};
+  static constexpr double halves_factor[2] = {0.885, 1.1};  // 1024^3: 41.2 us measured on the 64x64 tile
   static constexpr CostOverheads over = {4.75, 8.04, 6.02e6, 0.0295};
 };
 
@@ -170,8 +206,8 @@ hipError_t launch_huge(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
 
 // Estimated microseconds for `tile` with the K range cut into `depth` slabs.
 template <typename T>
-inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t k, int64_t batch, bool ta,
-                          bool tb, int cus) {
+inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t k, int64_t batch, int cus,
+                          bool fused = false) {
   using C = CostModel<T>;
   const int bm = tile == TILE_256 ? 256 : tile == TILE_128 ? 128 : 64;
   const int bn = tile == TILE_64 ? 64 : tile == TILE_128 ? 128 : Tiles<T>::HUGE_BN;
@@ -183,8 +219,9 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
   const int64_t full = busiest / occ, rem = busiest % occ;
   double us_per_k = double(full) * per_k[occ - 1] + (rem ? per_k[rem - 1] : 0.0);
   const int64_t k_chunk = bk * ceil_div(k, int64_t(bk) * depth);
+  if (fused) us_per_k *= C::halves_factor[tile == TILE_128 ? 1 : 0];
   double us = us_per_k * double(k_chunk);
-  if (depth > 1) {
+  if (depth > 1 && !fused) {
     us += C::over.t_split + 2.0 * double(m) * double(n) * double(depth) * sizeof(T) / C::over.bw +
           C::over.c_depth * double(depth);
   } else {
@@ -194,7 +231,7 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
 }
 
 template <typename T>
-inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, bool ta, bool tb, int cus) {
+inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
   // Batches of tiny matrices (the shapes the reference's interleaved layout exists
   // for): a 64x64 tile would be mostly padding.  Up to 16x16 one lane per C element
   // wins (4^3 x 65536: 5.6 us against 244; 16^3 x 8192: 14 against 36), up to 32x32 a
@@ -206,7 +243,7 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, bool ta, b
   Plan best = {TILE_64, 1};
   double best_us = 1e300;
   for (int tile = TILE_64; tile <= TILE_256; ++tile) {
-    const double us = estimate_us<T>(tile, 1, m, n, k, batch, ta, tb, cus);
+    const double us = estimate_us<T>(tile, 1, m, n, k, batch, cus);
     if (us < best_us) best_us = us, best = {tile, 1};
   }
   if (batch != 1) return best;
@@ -221,10 +258,25 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, bool ta, b
     for (int depth : depths) {
       if (k / depth < 64) break;                                                   // slabs of at least 64
       if (double(m) * double(n) * depth * sizeof(T) > double(1u << 30)) break;     // cube of at most 1 GiB
-      const double us = estimate_us<T>(tile, depth, m, n, k, 1, ta, tb, cus);
+      const double us = estimate_us<T>(tile, depth, m, n, k, 1, cus);
       if (us < split_us) split_us = us, split = {tile, depth};
     }
-  return split_us < 0.9 * best_us ? split : best;
+  Plan chosen = split_us < 0.9 * best_us ? split : best;
+  double chosen_us = split_us < 0.9 * best_us ? split_us : best_us;
+  // Two slabs can also live in one workgroup of the 64x64 / 128x128 tiles: no cube, one
+  // launch, twice the wavefronts per SIMD.  Only where the tiles alone leave at least
+  // half of a compute unit's workgroup slots empty (1024^3 fp64 56.7 -> 41.2 us; fp32
+  // 28.9 -> 26.6 and 2048^3 fp32 156 -> 138, which the 10 % rule for K cuts turns down);
+  // with more tiles it loses to the plain launch.
+  for (int tile = TILE_64; tile <= TILE_128; ++tile) {
+    const int bk = tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
+    const int edge = tile == TILE_128 ? 128 : 64, occ = tile == TILE_128 ? 2 : 4;
+    if (k % (2 * bk) != 0 || k < 512) continue;  // short K: the hand-over at the end is not free
+    if (ceil_div(m, edge) * ceil_div(n, edge) * 2 > int64_t(cus) * occ) continue;
+    const double us = estimate_us<T>(tile, 2, m, n, k, 1, cus, true);
+    if (us < 0.9 * best_us && us < chosen_us) chosen_us = us, chosen = {tile, 2, true};
+  }
+  return chosen;
 }
 
 template <typename T>
@@ -301,9 +353,10 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
 
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
 
-  Plan plan = plan_gemm<T>(p.m, p.n, p.k, p.batch, p.ta, p.tb, cus);
+  Plan plan = plan_gemm<T>(p.m, p.n, p.k, p.batch, cus);
   // A pinned family overrides the planner (testing / tuning hook).
   const int pin_depth = h->kernel_param & 0xffff, pin_tile = (h->kernel_param >> 16) & 0xff;
+  const bool pin_fused = (h->kernel_param >> 24) & 1;
   switch (h->kernel_override) {
     case SBAMD_KERNEL_AUTO: break;
     case SBAMD_KERNEL_LARGE: plan = {TILE_128, 1}; break;
@@ -315,6 +368,8 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       if (pin_tile >= TILE_64 && pin_tile <= TILE_256) plan.tile = pin_tile;
       else if (plan.tile > TILE_256) plan.tile = TILE_64;
       if (pin_depth > 0) plan.depth = pin_depth;
+      plan.fused = pin_fused;
+      if (pin_fused) plan.depth = 2;
       break;
     default: return hipErrorInvalidValue;
   }
@@ -334,6 +389,18 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   const int64_t k_chunk = std::max<int64_t>(bk, bk * ceil_div(p.k, int64_t(bk) * depth));
   depth = std::max<int64_t>(1, ceil_div(p.k, k_chunk));
 
+  if (depth == 2 && plan.fused && plan.tile != TILE_256 && p.k % (2 * bk) == 0) {
+    GemmArgs<T> gp = g;
+    gp.k_chunk = p.k / 2;
+    hipError_t e = plan.tile == TILE_128
+                       ? launch_halves<T, 128, 128, Tiles<T>::LARGE_BK, Tiles<T>::LARGE_WM, 2, sizeof(T) == 4 ? 4 : 2>(
+                             gp, p.ta, p.tb, h->stream)
+                       : launch_halves<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream);
+    h->last_kernel = SBAMD_KERNEL_SPLITK;
+    h->last_depth = 2;
+    h->last_k_chunk = gp.k_chunk;
+    return e;
+  }
   if (depth > 1) {
     const int64_t slice = p.m * p.n;
     hipError_t e = ensure_scratch(h, size_t(slice) * depth * sizeof(T));

@@ -716,6 +716,105 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   }
 }
 
+// ------------------------------------------ two K halves in one workgroup
+// Split-K with depth 2 without the cube: the workgroup holds two sets of WM x WN
+// wavefronts, set 0 works on the first half of K and set 1 on the second, each with
+// its own pair of LDS buffers, in lockstep (the halves are equal and whole K steps,
+// so both sets run the same number of steps and meet at the same barriers).  At the
+// end set 1 hands alpha * acc over through LDS and set 0 stores
+//     (alpha * acc0 + alpha * acc1) + beta * C,
+// which is, rounding for rounding, what the cube route produces for two slabs
+// (splitk_reduce_kernel): the same result without the second launch and without
+// writing and re-reading the partial sums through HBM.  It doubles the wavefronts per
+// SIMD for shapes whose tiles alone leave the matrix pipes half idle (one 4-wave
+// workgroup per compute unit).  The host checks k % (2 * BK) == 0 and sets
+// g.k_chunk = k / 2.
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC>
+__global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
+    gemm_mfma_halves_kernel(const GemmArgs<T> g) {
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
+  using M = Mfma<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SBAMD_LDS T* smem = (SBAMD_LDS T*)smem_raw;
+
+  const int half = threadIdx.x / K::NT;  // wave-uniform: NT is a multiple of 64
+  const int tid = threadIdx.x - half * K::NT;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM;
+  const int wn = wave / WM;
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = logical / ntiles;
+  int tm, tn;
+  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
+  const int64_t m0 = int64_t(tm) * BM;
+  const int64_t n0 = int64_t(tn) * BN;
+  const T* a = g.a + int64_t(z) * g.stride_a;
+  const T* b = g.b + int64_t(z) * g.stride_b;
+  T* c = g.c + int64_t(z) * g.stride_c;
+  const int64_t k_begin = int64_t(half) * g.k_chunk;
+  const int64_t k_end = k_begin + g.k_chunk;
+
+  GemmBody<T, BM, BN, BK, WM, WN, TA, TB> body;
+#pragma unroll
+  for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) body.acc[i][j][r] = T(0);
+
+  const int frag_mn = M::lane_mn(lane);
+  const int a_mn = wm * K::WTM + frag_mn;
+  const int b_mn = wn * K::WTN + frag_mn;
+  SBAMD_LDS T* mine = smem + half * (2 * K::STAGE_ELEMS);
+  const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
+  const bool clampable = (TA || g.m % M::V == 0) && (!TB || g.n % M::V == 0);
+  if ((interior || clampable) && g.vec_a && g.vec_b) {
+    body.run_pipelined(g, a, b, m0, n0, k_begin, k_end, mine, tid, a_mn, b_mn);
+  } else {
+    body.run_edge(g, a, b, m0, n0, k_begin, k_end, mine, tid, a_mn, b_mn);
+  }
+
+  // hand-over: [wave][subtile][register][lane], lane fastest
+  const T alpha = g.alpha, beta = g.beta;
+  __syncthreads();
+  SBAMD_LDS T* slot = smem + (wave * K::MI * K::NI * M::NACC) * 64 + lane;
+  if (half == 1) {
+#pragma unroll
+    for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) slot[((i * K::NI + j) * M::NACC + r) * 64] = alpha * body.acc[i][j][r];
+  }
+  __syncthreads();
+  if (half == 1) return;
+  const bool read_c = !g.beta_zero;
+#pragma unroll
+  for (int i = 0; i < K::MI; ++i) {
+    const int64_t mm = m0 + a_mn + i * M::T;
+#pragma unroll
+    for (int j = 0; j < K::NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < M::NACC; ++r) {
+        const int64_t nn = n0 + wn * K::WTN + j * M::T + M::acc_i(r, lane);
+        const T first = alpha * body.acc[i][j][r];
+        T out = first + slot[((i * K::NI + j) * M::NACC + r) * 64];
+        if (mm < g.m && nn < g.n) {
+          T* p = c + mm + nn * g.ldc;
+          if (read_c) {
+            const T bc = beta * (*p);
+            out = out + bc;
+          }
+          *p = out;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------ chunked-accumulation GEMM
 // C <- the result of k / CHUNK successive GEMM calls, chunk q being
 //     C <- -1 * op(A)[:, chunk q] * op(B)[chunk q, :] + beta_q * C,

@@ -178,10 +178,6 @@ def verify_gemm_strided(h, dtype, offset, batch, m, n, k, transa, transb, alpha,
     b_m = fill_random(rng, size_b + (batch - 1) * stride_b + offset, dtype)
     c_m = fill_random(rng, size_c + (batch - 1) * stride_c + offset, dtype)
 
-    c_orc = c_m.copy()
-    st = oracle.gemm_backend(transa, transb, m, n, k, alpha, a_m, lda, stride_a, b_m, ldb, stride_b, beta, c_orc,
-                             ldc, stride_c, batch=batch, a_off=offset, b_off=offset, c_off=offset)
-    assert st == 0
     c_blas = c_m.copy()
     for i in range(batch):
         openblas_gemm(transa, transb, m, n, k, alpha, a_m, i * stride_a + offset, lda, b_m,
@@ -193,6 +189,14 @@ def verify_gemm_strided(h, dtype, offset, batch, m, n, k, transa, transb, alpha,
                                         batch, deps)
 
     c_gpu = run_device(h, call, a_m, b_m, c_m)
+    # the oracle replays the K cut the library reports (only a single item is ever cut)
+    depth, k_chunk = h.last_splitk()
+    form = oracle.FORM_SPLITK if depth > 1 else oracle.FORM_REF
+    c_orc = c_m.copy()
+    st = oracle.gemm_backend(transa, transb, m, n, k, alpha, a_m, lda, stride_a, b_m, ldb, stride_b, beta, c_orc,
+                             ldc, stride_c, batch=batch, form=form, depth=depth, k_chunk=k_chunk,
+                             a_off=offset, b_off=offset, c_off=offset)
+    assert st == 0
     what = (f"strided {np.dtype(dtype).name} off={offset} batch={batch} {m}x{n}x{k} {transa}{transb} "
             f"a={alpha} b={beta} strides x{sa_mul},{sb_mul},{sc_mul}")
     assert_reference_predicate(c_gpu, c_blas, what)

@@ -69,3 +69,30 @@ def test_config4_shape_sample(sb_handle):
     assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK
     depth, k_chunk = sb_handle.last_splitk()
     assert depth > 1 and depth * k_chunk >= 65536
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("tile", [1, 2], ids=["64x64", "128x128"])
+def test_two_halves_in_one_workgroup(sb_handle, tile, dtype):
+    # Depth 2 with both K halves inside one workgroup (parameter bit 24) must give the bits of the cube
+    # route with two slabs -- (alpha*S0 + alpha*S1) + beta*C -- on interior tiles, ragged edges, odd
+    # leading dimensions (element loads) and every transpose; a K that does not split into whole K
+    # steps falls back to the cube route.
+    sb_handle.set_kernel(_lib.KERNEL_SPLITK, 2 | (tile << 16) | (1 << 24))
+    try:
+        for (m, n, k), ta, tb in itertools.product([(64, 64, 128), (128, 256, 512), (200, 130, 1024), (7, 9, 192),
+                                                    (257, 63, 640)], "nt", "nt"):
+            for alpha, beta, ldm in ((1.5, 0.5, 1), (2.0, 0.0, 3)):
+                verify_gemm(sb_handle, dtype, 0, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
+                assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK
+                assert sb_handle.last_splitk() == (2, k // 2)
+        verify_gemm(sb_handle, dtype, 0, 1, 65, 126, 1000, "n", "t", 1.5, 0.5, 1, 1, 1)
+        assert sb_handle.last_splitk()[0] == 2
+    finally:
+        sb_handle.set_kernel(_lib.KERNEL_AUTO)
+
+
+def test_planner_uses_the_halves_for_a_half_filled_chip(sb_handle):
+    # 1024^3 in fp64: 256 tiles of 64x64 leave three of four workgroup slots per compute unit empty.
+    verify_gemm(sb_handle, np.float64, 0, 1, 1024, 1024, 1024, "n", "n", 1.5, 0.5, 1, 1, 1)
+    assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK and sb_handle.last_splitk() == (2, 512)
