@@ -92,7 +92,7 @@ hipError_t launch_halves(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
 // The biggest tile: 256 x 256 (float) / 256 x 128 (double), eight waves as 4 (M) x 2 (N).
 // With both operands transposed the fp32 kernel mirrors the wave grid to 2 x 4: A is then
 // the K-major operand and B the N-major one, and the fragment traffic per wave is that of
-// the untransposed case with the roles of M and N swapped.
+// the untransposed case with the roles of M and N swapped.  NN uses 2 x 4 as well (measured).
 template <typename T>
 hipError_t launch_huge(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream);
 
@@ -194,11 +194,15 @@ struct CostModel<double> {
 template <typename T>
 hipError_t launch_huge(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
   if constexpr (sizeof(T) == 4) {
-    if (ta && tb) {
+    // 2 x 4 waves (128 x 64 each): TT, where it mirrors NN's fragment traffic, and NN itself, where it
+    // measured 0.7 % faster than 4 x 2 in alternating runs (8192^3: 143.6 against 142.6 TFLOP/s) and
+    // needs no spills; NT measured 1.4 % slower that way and keeps 4 x 2, as does TN.
+    if (ta == tb) {
       g.tiles_m = int32_t(ceil_div(g.m, 256));
       g.tiles_n = int32_t(ceil_div(g.n, 256));
-      return launch_one<T, 256, 256, Tiles<T>::HUGE_BK, 2, 4, Tiles<T>::HUGE_OCC, true, true>(
-          g, g.split_k > 1 ? g.split_k : g.batch, stream);
+      const int64_t nz = g.split_k > 1 ? g.split_k : g.batch;
+      return ta ? launch_one<T, 256, 256, Tiles<T>::HUGE_BK, 2, 4, Tiles<T>::HUGE_OCC, true, true>(g, nz, stream)
+                : launch_one<T, 256, 256, Tiles<T>::HUGE_BK, 2, 4, Tiles<T>::HUGE_OCC, false, false>(g, nz, stream);
     }
   }
   return launch_tile<T, 256, Tiles<T>::HUGE_BN, Tiles<T>::HUGE_BK, 4, 2, Tiles<T>::HUGE_OCC>(g, ta, tb, stream);

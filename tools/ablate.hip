@@ -61,6 +61,10 @@ int run(const char* name, int n, int reps = 5) {
 
 int main() {
   if (run<float, 256, 256, 16, 4, 2, 2>("f32 256x256x16", 8192)) return 1;
+  for (int round = 0; round < 3; ++round) {
+    if (run<float, 256, 256, 16, 2, 4, 2>("f32 256x256x16 (waves 2x4)", 8192, 10)) return 1;
+    if (run<float, 256, 256, 16, 4, 2, 2>("f32 256x256x16 (waves 4x2)", 8192, 10)) return 1;
+  }
   if (run<float, 256, 256, 16, 4, 4, 4>("f32 256x256x16 (16 waves)", 8192)) return 1;
   if (run<float, 256, 256, 32, 4, 4, 4>("f32 256x256x32 (16 waves)", 8192)) return 1;
   if (run<float, 256, 128, 32, 4, 2, 1>("f32 256x128x32", 8192)) return 1;
