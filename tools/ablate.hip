@@ -61,6 +61,8 @@ int run(const char* name, int n, int reps = 5) {
 
 int main() {
   if (run<float, 256, 256, 16, 4, 2, 2>("f32 256x256x16", 8192)) return 1;
+  if (run<float, 256, 256, 32, 2, 4, 2>("f32 256x256x32 (waves 2x4)", 8192, 10)) return 1;
+  if (run<float, 256, 256, 8, 2, 4, 2>("f32 256x256x8 (waves 2x4)", 8192, 10)) return 1;
   for (int round = 0; round < 3; ++round) {
     if (run<float, 256, 256, 16, 2, 4, 2>("f32 256x256x16 (waves 2x4)", 8192, 10)) return 1;
     if (run<float, 256, 256, 16, 4, 2, 2>("f32 256x256x16 (waves 4x2)", 8192, 10)) return 1;
