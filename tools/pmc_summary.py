@@ -17,7 +17,7 @@ for path in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            if "gemm" not in k and "reduce" not in k:
+            if "gemm" not in k and "reduce" not in k and "trsm" not in k:
                 continue
             acc[k.split("(")[0][:90]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
