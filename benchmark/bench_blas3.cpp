@@ -300,6 +300,7 @@ const char* kernel_name(int k) {
     case SBAMD_KERNEL_HUGE: return "huge";
     case SBAMD_KERNEL_INTERLEAVED: return "interleaved";
     case SBAMD_KERNEL_TINY: return "tiny";
+    case SBAMD_KERNEL_STREAM: return "stream";
     default: return "-";
   }
 }

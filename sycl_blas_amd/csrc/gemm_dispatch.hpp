@@ -58,6 +58,52 @@ hipError_t launch_tile(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
             : launch_one<T, BM, BN, BK, WM, WN, OCC, false, false>(g, nz, stream);
 }
 
+// Batches of one-tile, one-step items on a fixed set of workgroups (gemm_batch_stream_kernel).
+template <typename T, int BK, int OCC, bool TA, bool TB, bool READ_C, bool NT_LOADS>
+hipError_t launch_stream_nt(const GemmArgs<T>& g, int cus, hipStream_t stream) {
+  using K = GemmTile<T, 64, 64, BK, 2, 2, TA, TB>;
+  auto kernel = gemm_batch_stream_kernel<T, 64, BK, TA, TB, READ_C, NT_LOADS, OCC>;
+  constexpr size_t lds = K::LDS_BYTES / 2;  // one stage
+  static_assert(lds * OCC <= 160 * 1024, "the resident workgroups must fit the LDS");
+  static PerDeviceOnce lds_limit;
+  hipError_t e = lds_limit.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(lds));
+  });
+  if (e != hipSuccess) return e;
+  const int64_t grid = std::min<int64_t>(g.batch, int64_t(cus) * OCC);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, stream, g);
+  return hipGetLastError();
+}
+
+template <typename T, int BK, int OCC, bool TA, bool TB, bool READ_C>
+hipError_t launch_stream_one(const GemmArgs<T>& g, int cus, hipStream_t stream) {
+  // operands that will not stay in the Infinity Cache anyway are loaded non-temporally
+  const double bytes = double(g.batch) * sizeof(T) *
+                       (double(g.m) * double(g.k) + double(g.k) * double(g.n) + (READ_C ? 2.0 : 1.0) * double(g.m) * double(g.n));
+  return bytes > 320e6 ? launch_stream_nt<T, BK, OCC, TA, TB, READ_C, true>(g, cus, stream)
+                       : launch_stream_nt<T, BK, OCC, TA, TB, READ_C, false>(g, cus, stream);
+}
+
+template <typename T, int BK, int OCC, bool READ_C>
+hipError_t launch_stream_rc(const GemmArgs<T>& g, bool ta, bool tb, int cus, hipStream_t stream) {
+  // fp32 with both operands K-major needs a few registers more than four workgroups per unit leave
+  constexpr int OCC_TN = (sizeof(T) == 4 && OCC > 3) ? 3 : OCC;
+  if (ta) {
+    return tb ? launch_stream_one<T, BK, OCC, true, true, READ_C>(g, cus, stream)
+              : launch_stream_one<T, BK, OCC_TN, true, false, READ_C>(g, cus, stream);
+  }
+  return tb ? launch_stream_one<T, BK, OCC, false, true, READ_C>(g, cus, stream)
+            : launch_stream_one<T, BK, OCC, false, false, READ_C>(g, cus, stream);
+}
+
+template <typename T, int BK, int OCC>
+hipError_t launch_stream(const GemmArgs<T>& g, bool ta, bool tb, int cus, hipStream_t stream) {
+  // the C operands of an item wait in registers during its matrix work: one workgroup fewer per unit
+  return g.beta_zero ? launch_stream_rc<T, BK, OCC, false>(g, ta, tb, cus, stream)
+                     : launch_stream_rc<T, BK, (OCC > 2 ? OCC - 1 : OCC), true>(g, ta, tb, cus, stream);
+}
+
 // Both halves of K in one workgroup (gemm_mfma_halves_kernel); g.k_chunk = k / 2.
 template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB>
 hipError_t launch_halves_one(const GemmArgs<T>& g, hipStream_t stream) {
@@ -139,12 +185,12 @@ template <typename T>
 struct Tiles;
 template <>
 struct Tiles<float> {
-  static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 256, HUGE_OCC = 2, TINY_BK = 16;
+  static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 256, HUGE_OCC = 2, TINY_BK = 16, STREAM_OCC = 4;
   static constexpr int LARGE_WM = 4;  // 128 x 128 as eight waves of 32 x 64: 4-6 % faster than four of 64 x 64 at 2048^3..4096^3
 };
 template <>
 struct Tiles<double> {
-  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 128, HUGE_OCC = 1, TINY_BK = 8;
+  static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 128, HUGE_OCC = 1, TINY_BK = 8, STREAM_OCC = 2;
   static constexpr int LARGE_WM = 2;  // four waves of 64 x 64 (eight waves gain nothing in fp64)
 };
 
@@ -442,6 +488,15 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       // Short K (the batched 64x64x64 class): stage the whole K range at once --
       // one load burst, one barrier, no K loop -- so a CU overlaps the loads of
       // some items with the matrix work of others.
+      // More items than resident workgroups: a fixed set of workgroups walks the batch
+      // with the next item's operands requested ahead of the current item's matrix work.
+      if (p.k == Tiles<T>::ONESHOT_BK && p.m <= 64 && p.n <= 64 && g.vec_a && g.vec_b &&
+          (p.ta || p.m % Mfma<T>::V == 0) && (!p.tb || p.n % Mfma<T>::V == 0) &&
+          std::max({p.lda, p.ldb, p.ldc}) < (int64_t(1) << 22) &&  // byte offsets inside an item fit 32 bits
+          p.batch > int64_t(cus) * Tiles<T>::STREAM_OCC && h->kernel_override == SBAMD_KERNEL_AUTO) {
+        h->last_kernel = SBAMD_KERNEL_STREAM;
+        return launch_stream<T, Tiles<T>::ONESHOT_BK, Tiles<T>::STREAM_OCC>(g, p.ta, p.tb, cus, h->stream);
+      }
       if (p.k <= Tiles<T>::ONESHOT_BK && p.k > Tiles<T>::SMALL_BK)
         return launch_tile<T, 64, 64, Tiles<T>::ONESHOT_BK, 2, 2, sizeof(T) == 4 ? 4 : 2>(g, p.ta, p.tb, h->stream);
       return launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(g, p.ta, p.tb, h->stream);

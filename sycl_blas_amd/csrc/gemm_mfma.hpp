@@ -815,6 +815,152 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
   }
 }
 
+// ------------------------------------------- batches of one-tile, one-step items
+// Strided batches whose items are a single tile with a single K step (m, n <= BMN, k == BK: the
+// batched 64x64x64 class) are bound by HBM, not by the matrix pipes: each item moves three
+// tiles and does one K step of work.  A workgroup per item leaves the loads of an item exposed
+// behind its launch; here a fixed set of workgroups walks the batch (item z, z + grid, ...) and
+// the operands of the NEXT item are requested before the matrix work of the current one starts,
+// so every resident workgroup keeps a whole item in flight all the time.  One LDS stage: the
+// registers are the second buffer.  Per element the arithmetic is the chain of the tile kernel
+// (same fragments, same order, same epilogue), so the two kernels agree bit for bit.  The host
+// checks k == BK, 16-byte-loadable operands, that no vector straddles the edge and that the
+// byte offsets inside an item fit 32 bits.  NT_LOADS marks the operand loads non-temporal
+// (cache policy bit 1 of the buffer load): a batch larger than the 256 MB Infinity Cache
+// streams past it (fp32 x 16384 items: 156 -> 136 us), a smaller one is better off cached.
+template <typename T, int BMN, int BK, bool TA, bool TB, bool READ_C, bool NT_LOADS, int OCC>
+__global__ void __launch_bounds__(256, OCC)
+    gemm_batch_stream_kernel(const GemmArgs<T> g) {
+  using K = GemmTile<T, BMN, BMN, BK, 2, 2, TA, TB>;
+  using M = Mfma<T>;
+  using LoadA = typename K::LoadA;
+  using LoadB = typename K::LoadB;
+  using vec_t = typename M::vec_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SBAMD_LDS T* smem = (SBAMD_LDS T*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave & 1;
+  const int wn = wave >> 1;
+  const int frag_mn = M::lane_mn(lane);
+  const int a_mn = wm * K::WTM + frag_mn;
+  const int b_mn = wn * K::WTN + frag_mn;
+  const T alpha = g.alpha, beta = g.beta;
+
+  // Where a thread's vectors sit inside an item does not depend on the item: 32-bit byte
+  // offsets computed once, added to the item's (uniform) base address by the load itself.
+  // Rows / vectors past the edge point at the last valid one, as in the tile kernel.
+  const uint32_t m = uint32_t(g.m), n = uint32_t(g.n);
+  const uint32_t lda = uint32_t(g.lda), ldb = uint32_t(g.ldb), ldc = uint32_t(g.ldc);
+  uint32_t offa[LoadA::NV], offb[LoadB::NV];
+#pragma unroll
+  for (int i = 0; i < LoadA::NV; ++i) {
+    const uint32_t v = tid + i * 256, row = v / LoadA::PER_ROW, col = (v % LoadA::PER_ROW) * M::V;
+    offa[i] = uint32_t(sizeof(T)) * (TA ? col + (row < m ? row : m - 1) * lda : (col < m ? col : m - M::V) + row * lda);
+  }
+#pragma unroll
+  for (int i = 0; i < LoadB::NV; ++i) {
+    const uint32_t v = tid + i * 256, row = v / LoadB::PER_ROW, col = (v % LoadB::PER_ROW) * M::V;
+    offb[i] = uint32_t(sizeof(T)) * (!TB ? col + (row < n ? row : n - 1) * ldb : (col < n ? col : n - M::V) + row * ldb);
+  }
+  const uint32_t c_row = a_mn;                                   // this lane's M index
+  const uint32_t c_col0 = wn * K::WTN + M::acc_i(0, lane);       // its first N index
+  const uint32_t offc0 = uint32_t(sizeof(T)) * (c_row + c_col0 * ldc);
+
+  GemmBody<T, BMN, BMN, BK, 2, 2, TA, TB> body;
+  // Buffer addressing: the item's base goes into a (uniform) descriptor and the per-thread
+  // part stays a 32-bit offset, so no 64-bit address per vector has to live across the
+  // matrix work; accesses whose offset is out of range are dropped by the range check,
+  // which is how elements past the edge of C are masked (offset all ones).
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int RANGE = 0x7fffffff;
+  auto request = [&](int64_t item) {
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.a + item * g.stride_a), 0, RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.b + item * g.stride_b), 0, RANGE, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < LoadA::NV; ++i) {
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(ra, int(offa[i]), 0, NT_LOADS ? 2 : 0);
+      const vec_t vv = __builtin_bit_cast(vec_t, raw);
+#pragma unroll
+      for (int e = 0; e < M::V; ++e) body.la.reg[i][e] = vv[e];
+    }
+#pragma unroll
+    for (int i = 0; i < LoadB::NV; ++i) {
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rb, int(offb[i]), 0, NT_LOADS ? 2 : 0);
+      const vec_t vv = __builtin_bit_cast(vec_t, raw);
+#pragma unroll
+      for (int e = 0; e < M::V; ++e) body.lb.reg[i][e] = vv[e];
+    }
+  };
+  // one C element of this lane: byte offset, or all ones past the edge
+  auto c_offset = [&](int i, int j, int r) -> int {
+    const uint32_t dm = i * M::T, dn = j * M::T + M::acc_i(r, 0);
+    const bool live = c_row + dm < m && c_col0 + dn < n;
+    return live ? int(offc0 + uint32_t(sizeof(T)) * (dm + dn * ldc)) : -1;
+  };
+  auto c_load = [&](__amdgpu_buffer_rsrc_t rc, int off) -> T {
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
+    else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rc, off, 0, 0));
+  };
+  auto c_store = [&](__amdgpu_buffer_rsrc_t rc, int off, T v) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rc, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rc, off, 0, 0);
+  };
+
+  int64_t z = blockIdx.x;
+  if (z >= g.batch) return;  // uniform over the workgroup
+  request(z);
+
+  for (;;) {
+    body.la.store(smem, tid);
+    body.lb.store(smem + K::A_ELEMS, tid);
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.c + z * g.stride_c, 0, RANGE, 0x00020000);
+    // beta * C operands first, then the next item's tiles: the memory counter retires
+    // in order, so the epilogue can wait for the former while the latter stay in flight.
+    T cin[K::MI][K::NI][M::NACC];
+    if (READ_C) {
+#pragma unroll
+      for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+          for (int r = 0; r < M::NACC; ++r) cin[i][j][r] = c_load(rc, c_offset(i, j, r));
+    }
+    const int64_t zn = z + gridDim.x;
+    if (zn < g.batch) request(zn);
+    __builtin_amdgcn_sched_barrier(0);  // the requests go out before the matrix work
+#pragma unroll
+    for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) body.acc[i][j][r] = T(0);
+    body.template compute<0>(smem, smem + K::A_ELEMS, a_mn, b_mn, lane);
+#pragma unroll
+    for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) {
+          T out = alpha * body.acc[i][j][r];
+          if (READ_C) {
+            const T bc = beta * cin[i][j][r];
+            out = out + bc;
+          }
+          c_store(rc, c_offset(i, j, r), out);
+        }
+    if (zn >= g.batch) break;
+    z = zn;
+    __syncthreads();  // every wave is done with the fragments before the stage is overwritten
+  }
+}
+
 // ------------------------------------------------ chunked-accumulation GEMM
 // C <- the result of k / CHUNK successive GEMM calls, chunk q being
 //     C <- -1 * op(A)[:, chunk q] * op(B)[chunk q, :] + beta_q * C,

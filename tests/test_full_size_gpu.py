@@ -91,7 +91,7 @@ def test_config3_full_batch(sb_handle):
     c_g = helper.allocate(h, np.float32, per * batch)
     sb._gemm_strided_batched(h, "n", "n", m, m, m, 1.0, a_g, m, per, b_g, m, per, 0.0, c_g, m, per, batch)
     h.wait()
-    assert h.last_kernel() == _lib.KERNEL_SMALL
+    assert h.last_kernel() == _lib.KERNEL_STREAM
     a, b, got = (to_host(h, x, np.float32, per * batch) for x in (a_g, b_g, c_g))
     want = np.zeros(per * batch, np.float32)
     assert oracle.gemm_backend("n", "n", m, m, m, 1.0, a, m, per, b, m, per, 0.0, want, m, per, batch=batch) == 0

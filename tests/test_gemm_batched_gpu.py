@@ -107,3 +107,31 @@ def test_interleaved_items_big_enough_to_repack(sb_handle, dtype):
     # just below the threshold the lanes-over-batch kernel still runs
     verify_gemm(sb_handle, dtype, 0, 4, 31, 200, 200, "n", "n", 1.0, 1.0, 1, 1, 1, batch_type=interleaved)
     assert sb_handle.last_kernel() == _lib.KERNEL_INTERLEAVED
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_long_batches_of_single_tile_items(sb_handle, dtype):
+    # More 64x64x64-class items than a chip holds workgroups: resident workgroups walk the batch with the
+    # next item's operands requested ahead.  Same chain per element as the tile kernel: whole buffers
+    # (padding between items and rows included) must equal the oracle bit for bit.  Batch sizes that do
+    # and do not divide over the workgroups, edges along M and N, padded leading dimensions, a
+    # broadcast operand, C read and not read.
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    v = 16 // np.dtype(dtype).itemsize
+    for ta, tb in itertools.product("nt", "nt"):
+        verify_gemm_strided(sb_handle, dtype, 0, 1100, 64, 64, 64, ta, tb, 1.0, 0.0, 1, 1, 1, 1, 1, 1)
+        assert sb_handle.last_kernel() == _lib.KERNEL_STREAM
+        verify_gemm_strided(sb_handle, dtype, v, 2051, 64, 64, 64, ta, tb, 1.5, 0.5, 1, 1, 1, 1, 1, 1)
+        assert sb_handle.last_kernel() == _lib.KERNEL_STREAM
+        verify_gemm_strided(sb_handle, dtype, 0, 1300, 60, 44, 64, ta, tb, -1.0, 7.0, 2, 1, 3, 1, 0, 2)
+        assert sb_handle.last_kernel() == _lib.KERNEL_STREAM
+        verify_gemm_strided(sb_handle, dtype, 2 * v, 1025, 4, 64, 64, ta, tb, 3.0, 0.0, 1, 2, 1, 2, 1, 1)
+        assert sb_handle.last_kernel() == _lib.KERNEL_STREAM
+    # what the walking kernel does not take keeps the tile kernel: unaligned operands, a vector that
+    # would straddle the edge, another K
+    verify_gemm_strided(sb_handle, dtype, 1, 1100, 64, 64, 64, "n", "n", 1.0, 0.0, 1, 1, 1, 1, 1, 1)
+    assert sb_handle.last_kernel() == _lib.KERNEL_SMALL
+    verify_gemm_strided(sb_handle, dtype, 0, 1100, 63, 64, 64, "n", "n", 1.0, 0.0, 1, 1, 1, 1, 1, 1)
+    assert sb_handle.last_kernel() == _lib.KERNEL_SMALL
+    verify_gemm_strided(sb_handle, dtype, 0, 1100, 64, 64, 48, "n", "n", 1.0, 0.0, 1, 1, 1, 1, 1, 1)
+    assert sb_handle.last_kernel() == _lib.KERNEL_SMALL
