@@ -240,6 +240,11 @@ struct CostModel<double> {
 template <typename T>
 hipError_t launch_huge(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
   if constexpr (sizeof(T) == 4) {
+    // K slabs streamed from HBM with A read along K: a K step of 32 fetches whole 128-byte lines of
+    // every row (16 fetches half a line per step, and rows a large power of two apart crowd the
+    // same memory channels).  256 x 256 x 4194304: TN 114.8 -> 133.5 TFLOP/s, TT 127.5 -> 131.5;
+    // NN (B read along K) measured no gain on the mirrored 128 x 256 x 32 tile and keeps 256 x 256 x 16.
+    if (g.split_k > 1 && ta) return launch_tile<T, 256, 128, 32, 4, 2, 1>(g, ta, tb, stream);
     // 2 x 4 waves (128 x 64 each): TT, where it mirrors NN's fragment traffic, and NN itself, where it
     // measured 0.7 % faster than 4 x 2 in alternating runs (8192^3: 143.6 against 142.6 TFLOP/s) and
     // needs no spills; NT measured 1.4 % slower that way and keeps 4 x 2, as does TN.

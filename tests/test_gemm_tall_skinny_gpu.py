@@ -96,3 +96,18 @@ def test_planner_uses_the_halves_for_a_half_filled_chip(sb_handle):
     # 1024^3 in fp64: 256 tiles of 64x64 leave three of four workgroup slots per compute unit empty.
     verify_gemm(sb_handle, np.float64, 0, 1, 1024, 1024, 1024, "n", "n", 1.5, 0.5, 1, 1, 1)
     assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK and sb_handle.last_splitk() == (2, 512)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_forced_split_on_the_biggest_tile(sb_handle, dtype):
+    # K slabs on the biggest tile family, every transpose (fp32 with A read along K takes a narrower tile
+    # with a deeper K step there), K cuts that are and are not whole K steps of either tile, ragged edges.
+    try:
+        for depth in (3, 4):
+            sb_handle.set_kernel(_lib.KERNEL_SPLITK, depth | (3 << 16))
+            for (m, n, k), ta, tb in itertools.product([(256, 256, 4096), (300, 200, 2064), (512, 260, 1000)], "nt", "nt"):
+                for alpha, beta, ldm in ((1.5, 0.5, 1), (2.0, 0.0, 3)):
+                    verify_gemm(sb_handle, dtype, 0, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
+                    assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK and sb_handle.last_splitk()[0] == depth
+    finally:
+        sb_handle.set_kernel(_lib.KERNEL_AUTO)
