@@ -4,7 +4,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sycl_blas_amd as sb  # noqa: E402
 from sycl_blas_amd import _lib, helper  # noqa: E402
 
