@@ -1,10 +1,11 @@
 """Developer probe: batches of 64x64x64 items, planner's choice (the walking-workgroup kernel)
 against the pinned one-workgroup-per-item kernel -- timing and bitwise agreement."""
+import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sycl_blas_amd as sb  # noqa: E402
 from sycl_blas_amd import _lib, helper  # noqa: E402
 

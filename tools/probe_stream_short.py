@@ -1,10 +1,11 @@
 """Developer probe: the 64x64x64 batches only (fp32 and fp64, NN and TN), planner's choice."""
+import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sycl_blas_amd as sb  # noqa: E402
 from sycl_blas_amd import _lib  # noqa: E402
 from probe_stream import run  # noqa: E402

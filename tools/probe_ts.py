@@ -1,9 +1,10 @@
 """Developer probe: the tall-skinny SGEMM 256 x 256 x 4194304 (all four layouts), planner's choice."""
+import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sycl_blas_amd as sb  # noqa: E402
 from sycl_blas_amd import _lib, helper  # noqa: E402
 
