@@ -270,7 +270,8 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
   const int occ = tile == TILE_256 ? 1 : tile == TILE_128 ? 2 : 4;
   const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : C::small_k;
   const int64_t wgs = ceil_div(m, bm) * ceil_div(n, bn) * batch * depth;
-  const int64_t busiest = ceil_div(wgs, cus);  // workgroups the fullest compute unit runs
+  // workgroups the fullest compute unit runs; the sets of a fused workgroup always share a unit
+  const int64_t busiest = fused ? ceil_div(wgs / depth, cus) * depth : ceil_div(wgs, cus);
   const int64_t full = busiest / occ, rem = busiest % occ;
   double us_per_k = double(full) * per_k[occ - 1] + (rem ? per_k[rem - 1] : 0.0);
   const int64_t k_chunk = bk * ceil_div(k, int64_t(bk) * depth);
