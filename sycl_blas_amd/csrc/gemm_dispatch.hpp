@@ -505,6 +505,11 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       }
       if (p.k <= Tiles<T>::ONESHOT_BK && p.k > Tiles<T>::SMALL_BK)
         return launch_tile<T, 64, 64, Tiles<T>::ONESHOT_BK, 2, 2, sizeof(T) == 4 ? 4 : 2>(g, p.ta, p.tb, h->stream);
+      // At most two workgroups per compute unit (what the deeper stages leave room for): the K step of 64
+      // halves the barriers and load waits per matrix instruction, which a unit with so few wavefronts
+      // cannot hide (alternating runs: fp64 1024^3 57.7 -> 52.8 us, 768^3 43.0 -> 38.8; fp32 1-2 %; same chain, same bits).
+      if (p.k >= 4 * Tiles<T>::ONESHOT_BK && ceil_div(p.m, 64) * ceil_div(p.n, 64) * p.batch <= 2 * int64_t(cus))
+        return launch_tile<T, 64, 64, Tiles<T>::ONESHOT_BK, 2, 2, sizeof(T) == 4 ? 4 : 2>(g, p.ta, p.tb, h->stream);
       return launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(g, p.ta, p.tb, h->stream);
   }
 }
