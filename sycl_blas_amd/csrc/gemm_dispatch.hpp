@@ -58,6 +58,44 @@ hipError_t launch_tile(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
             : launch_one<T, BM, BN, BK, WM, WN, OCC, false, false>(g, nz, stream);
 }
 
+// fp32 tiles staged global -> LDS directly (gemm_mfma_dma_kernel): K in whole K steps, both operands
+// 16-byte loadable, no vector straddling an edge.
+template <int BM, int BN, int BK, int WM, int WN, int OCC, int STAGES, bool TA, bool TB>
+hipError_t launch_dma_one(const GemmArgs<float>& g, int64_t nz, hipStream_t stream) {
+  auto kernel = gemm_mfma_dma_kernel<BM, BN, BK, WM, WN, TA, TB, OCC, STAGES>;
+  constexpr size_t lds = size_t(STAGES) * (BM + BN) * BK * sizeof(float);
+  static_assert(lds <= 160 * 1024, "the stages must fit the LDS");
+  static PerDeviceOnce lds_limit;
+  hipError_t e = lds_limit.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(lds));
+  });
+  if (e != hipSuccess) return e;
+  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * nz;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WM * WN * 64), lds, stream, g);
+  return hipGetLastError();
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int OCC, int STAGES>
+hipError_t launch_dma_tile(GemmArgs<float> g, hipStream_t stream) {
+  g.tiles_m = int32_t(ceil_div(g.m, BM));
+  g.tiles_n = int32_t(ceil_div(g.n, BN));
+  const int64_t nz = g.split_k > 1 ? g.split_k : g.batch;
+  return launch_dma_one<BM, BN, BK, WM, WN, OCC, STAGES, false, true>(g, nz, stream);  // A 'n', B 't' (dma_ok)
+}
+
+// Should the direct-to-LDS kernel take this launch?  (K range per slice in whole K steps of `bk`.)
+// Only with both operands M/N-contiguous (A 'n', B 't'): their linear [k][mn] image is read without bank
+// conflicts.  A K-contiguous operand can only be swizzled in 16-byte pieces, which leaves its fragment
+// reads two-way conflicted, and measured slower than the register-staged kernel with its padded rows
+// (1024^3 on 64x64 tiles: NT 30.1 -> 28.6 us, but NN 31.0 -> 32.0, TN 31.7 -> 34.2).
+template <typename T>
+inline bool dma_ok(const GemmArgs<T>& g, bool ta, bool tb, int64_t k_span, int bk) {
+  if constexpr (sizeof(T) != 4) return false;
+  return !ta && tb && g.vec_a && g.vec_b && k_span % bk == 0 && k_span >= 2 * bk && g.m % 4 == 0 && g.n % 4 == 0;
+}
+
 // Batches of one-tile, one-step items on a fixed set of workgroups (gemm_batch_stream_kernel).
 template <typename T, int BK, int OCC, bool TA, bool TB, bool READ_C, bool NT_LOADS>
 hipError_t launch_stream_nt(const GemmArgs<T>& g, int cus, hipStream_t stream) {
@@ -505,6 +543,12 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       }
       if (p.k <= Tiles<T>::ONESHOT_BK && p.k > Tiles<T>::SMALL_BK)
         return launch_tile<T, 64, 64, Tiles<T>::ONESHOT_BK, 2, 2, sizeof(T) == 4 ? 4 : 2>(g, p.ta, p.tb, h->stream);
+      // Operand tiles straight into LDS where the shape allows (fp32; parameter bit 0 of a pinned SMALL
+      // family keeps the register-staged kernel, for A/B runs).
+      if constexpr (sizeof(T) == 4) {
+        if (dma_ok(g, p.ta, p.tb, p.k, 32) && p.k >= 128 && !(h->kernel_override == SBAMD_KERNEL_SMALL && (h->kernel_param & 1)))
+          return launch_dma_tile<64, 64, 32, 2, 2, 3, 3>(g, h->stream);
+      }
       // At most two workgroups per compute unit (what the deeper stages leave room for): the K step of 64
       // halves the barriers and load waits per matrix instruction, which a unit with so few wavefronts
       // cannot hide (alternating runs: fp64 1024^3 57.7 -> 52.8 us, 768^3 43.0 -> 38.8; fp32 1-2 %; same chain, same bits).

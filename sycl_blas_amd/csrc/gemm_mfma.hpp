@@ -815,6 +815,205 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
   }
 }
 
+// ------------------------------------------- operand tiles straight into LDS (fp32)
+// The register-staged pipeline above spends a global load, a wait, an LDS store and their
+// address arithmetic per 16 bytes of operand; a compute unit that holds only a few wavefronts
+// (mid-size shapes: one or two 64x64 tiles per unit) cannot hide that (timing-only ablation at
+// 1024^3: 29 us, 19 us with the staging switched off).  Here the tiles go global -> LDS with
+// global_load_lds_dwordx4: no registers, no LDS store instruction, and the only wait is a counted
+// s_waitcnt in front of the one barrier per K step.  A load instruction writes 64 lanes x 16 bytes
+// = 1 KiB of LDS contiguously, so the images are linear:
+//   M/N-contiguous operand: [BK][BMN], exactly the register-staged image (fp32 needs no padding);
+//   K-contiguous operand:   [BMN][BK], rows of BK / 4 16-byte pieces; piece c of row r sits at
+//                           position c ^ ((r >> 1) & (BK / 4 - 1)), chosen by WHICH piece each lane
+//                           fetches.  A fragment is the dword pair (k, k + 2) of one piece.
+// The matrix instructions, their order and the epilogue are those of gemm_mfma_kernel, so the two
+// kernels agree bit for bit.  The host checks: K a multiple of BK, 16-byte-loadable operands, and
+// no 16-byte vector straddling an edge (rows / vectors past the edge are clamped as above).
+typedef __attribute__((address_space(1))) const void* dma_src_t;
+typedef __attribute__((address_space(3))) void* dma_dst_t;
+
+template <int BMN, int BK, int NWAVES, bool KMAJOR>
+struct DmaOperand {
+  static constexpr int ELEMS = BMN * BK;             // floats per image
+  static constexpr int PIECES = ELEMS * 4 / 1024;    // load instructions per image
+  static_assert(PIECES % NWAVES == 0, "the image splits evenly over the wavefronts");
+  static constexpr int PER_WAVE = PIECES / NWAVES;
+  static constexpr int ROW_PIECES = BK / 4;          // K-contiguous rows: 16-byte pieces per row
+  static constexpr int ROWS_PER_LOAD = 64 / ROW_PIECES;
+  static constexpr int KROWS_PER_LOAD = 256 / BMN;   // M/N-contiguous: k rows per load instruction
+
+  const float* src[PER_WAVE];
+
+  __device__ inline void init(const float* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim, int64_t k0,
+                              int wave, int lane) {
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+      const int j = wave + NWAVES * u;
+      if (KMAJOR) {
+        const int row = j * ROWS_PER_LOAD + lane / ROW_PIECES;
+        const int c = (lane % ROW_PIECES) ^ ((row >> 1) & (ROW_PIECES - 1));
+        int64_t mn = mn0 + row;
+        mn = mn < mn_lim ? mn : mn_lim - 1;
+        src[u] = x + mn * ld + k0 + c * 4;
+      } else {
+        const int krow = j * KROWS_PER_LOAD + lane / (BMN / 4);
+        int64_t mn = mn0 + (lane % (BMN / 4)) * 4;
+        mn = mn < mn_lim ? mn : mn_lim - 4;
+        src[u] = x + mn + (k0 + krow) * ld;
+      }
+    }
+  }
+
+  // Request the tile the pointers address into the image at `lds`, then move on one K step.
+  __device__ inline void issue(SBAMD_LDS float* lds, int64_t ld, int wave) {
+    const int64_t step = KMAJOR ? int64_t(BK) : int64_t(BK) * ld;
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+      __builtin_amdgcn_global_load_lds((dma_src_t)src[u], (dma_dst_t)(lds + (wave + NWAVES * u) * 256), 16, 0, 0);
+      src[u] += step;
+    }
+  }
+
+  // Operands of one lane for MFMA k-steps 2 * grp and 2 * grp + 1 (k = 4 grp + lk and 4 grp + 2 + lk).
+  __device__ static inline void fragment(const SBAMD_LDS float* lds, int grp, int mn, int lane, float (&out)[2]) {
+    const int lk = lane >> 5;
+    if (KMAJOR) {
+      const SBAMD_LDS float* p = lds + mn * BK + ((grp ^ ((mn >> 1) & (ROW_PIECES - 1))) << 2) + lk;
+      out[0] = p[0];
+      out[1] = p[2];
+    } else {
+      out[0] = lds[(4 * grp + lk) * BMN + mn];
+      out[1] = lds[(4 * grp + 2 + lk) * BMN + mn];
+    }
+  }
+};
+
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC, int STAGES>
+__global__ void __launch_bounds__(WM* WN * 64, OCC)
+    gemm_mfma_dma_kernel(const GemmArgs<float> g) {
+  using M = Mfma<float>;
+  constexpr int NWAVES = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32, NGRP = BK / 4;
+  using OpA = DmaOperand<BM, BK, NWAVES, TA>;
+  using OpB = DmaOperand<BN, BK, NWAVES, !TB>;
+  constexpr int STAGE = OpA::ELEMS + OpB::ELEMS;
+  constexpr int IN_FLIGHT = (STAGES - 2) * (OpA::PER_WAVE + OpB::PER_WAVE);  // loads that may stay out at the barrier
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+  SBAMD_LDS float* smem = (SBAMD_LDS float*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = logical / ntiles;
+  int tm, tn;
+  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
+  const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
+
+  const float* a = g.a;
+  const float* b = g.b;
+  float* c = g.c;
+  int64_t k_begin = 0, k_end = g.k;
+  if (g.split_k > 1) {
+    k_begin = int64_t(z) * g.k_chunk;
+    k_end = k_begin + g.k_chunk < g.k ? k_begin + g.k_chunk : g.k;
+    c += int64_t(z) * g.slice_stride;
+  } else {
+    a += int64_t(z) * g.stride_a;
+    b += int64_t(z) * g.stride_b;
+    c += int64_t(z) * g.stride_c;
+  }
+  const int nk = int((k_end - k_begin) / BK);  // whole K steps (host)
+
+  OpA oa;
+  OpB ob;
+  oa.init(a, g.lda, m0, g.m, k_begin, wave, lane);
+  ob.init(b, g.ldb, n0, g.n, k_begin, wave, lane);
+
+  M::acc_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int a_mn = wm * WTM + (lane & 31), b_mn = wn * WTN + (lane & 31);
+
+  // tiles 0 .. STAGES-2 go in flight; tile 0 has landed (this wave's pieces) before the barrier
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t)
+    if (t < nk) {
+      oa.issue(smem + t * STAGE, g.lda, wave);
+      ob.issue(smem + t * STAGE + OpA::ELEMS, g.ldb, wave);
+    }
+  if (nk >= STAGES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int cur = 0, fill = STAGES - 1;
+  for (int t = 0; t < nk; ++t) {
+    // the stage filled now was read during the previous step; every wave has passed that step's barrier
+    const bool more = t + STAGES - 1 < nk;
+    if (more) {
+      oa.issue(smem + fill * STAGE, g.lda, wave);
+      ob.issue(smem + fill * STAGE + OpA::ELEMS, g.ldb, wave);
+    }
+    const SBAMD_LDS float* as = smem + cur * STAGE;
+    const SBAMD_LDS float* bs = as + OpA::ELEMS;
+    float fa[2][MI][2], fb[2][NI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) OpA::fragment(as, 0, a_mn + i * 32, lane, fa[0][i]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) OpB::fragment(bs, 0, b_mn + j * 32, lane, fb[0][j]);
+#pragma unroll
+    for (int grp = 0; grp < NGRP; ++grp) {
+      const int cu = grp & 1, nx = cu ^ 1;
+      if (grp + 1 < NGRP) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) OpA::fragment(as, grp + 1, a_mn + i * 32, lane, fa[nx][i]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) OpB::fragment(bs, grp + 1, b_mn + j * 32, lane, fb[nx][j]);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = M::mma(fb[cu][j][e], fa[cu][i][e], acc[i][j]);
+    }
+    // this wave's pieces of tile t + 1 have landed; the newer tiles may stay in flight
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
+    fill = fill + 1 == STAGES ? 0 : fill + 1;
+  }
+
+  const float alpha = g.alpha, beta = g.beta;
+  const bool read_c = !g.beta_zero && g.split_k <= 1;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int64_t mm = m0 + a_mn + i * 32;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t nn = n0 + wn * WTN + j * 32 + M::acc_i(r, lane);
+        if (mm < g.m && nn < g.n) {
+          float* p = c + mm + nn * g.ldc;
+          float out = alpha * acc[i][j][r];
+          if (read_c) {
+            const float bc = beta * (*p);
+            out = out + bc;
+          }
+          *p = out;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------- batches of one-tile, one-step items
 // Strided batches whose items are a single tile with a single K step (m, n <= BMN, k == BK: the
 // batched 64x64x64 class) are bound by HBM, not by the matrix pipes: each item moves three

@@ -1,5 +1,5 @@
 """Developer probe: one GEMM shape, one kernel family, many launches (for counter passes).
-usage: probe_one.py M N K [family=0] [param=0] [reps=200] [dtype=f32]"""
+usage: probe_one.py M N K [family=0] [param=0] [reps=200] [dtype=f32] [trans=nn]"""
 import os
 import sys
 
@@ -14,6 +14,7 @@ fam = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 par = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 200
 dtype = np.float64 if len(sys.argv) > 7 and sys.argv[7] == "f64" else np.float32
+ta, tb = sys.argv[8] if len(sys.argv) > 8 else "nn"
 with sb.SB_Handle(0) as h:
     a_g = helper.allocate(h, dtype, m * k)
     b_g = helper.allocate(h, dtype, k * n)
@@ -21,7 +22,9 @@ with sb.SB_Handle(0) as h:
     helper.fill_uniform(h, a_g, m * k, 1)
     helper.fill_uniform(h, b_g, k * n, 2)
     h.set_kernel(fam, par)
-    call = lambda: sb._gemm(h, "n", "n", m, n, k, 1.0, a_g, m, b_g, k, 0.0, c_g, m)
+    lda = k if ta != "n" else m
+    ldb = n if tb != "n" else k
+    call = lambda: sb._gemm(h, ta, tb, m, n, k, 1.0, a_g, lda, b_g, ldb, 0.0, c_g, m)
     for _ in range(10):
         call()
     h.wait()
@@ -31,5 +34,5 @@ with sb.SB_Handle(0) as h:
     e1 = h.record_event()
     e1.wait()
     us = e0.elapsed_ms(e1) / reps * 1e3
-    print(f"{np.dtype(dtype).name} {m}x{n}x{k} family {fam} param {par}: {us:.1f} us {2.0 * m * n * k / us / 1e6:.1f} TFLOP/s "
+    print(f"{np.dtype(dtype).name} {ta}{tb} {m}x{n}x{k} family {fam} param {par}: {us:.1f} us {2.0 * m * n * k / us / 1e6:.1f} TFLOP/s "
           f"kernel={h.last_kernel()} cut={h.last_splitk()}")
