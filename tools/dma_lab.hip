@@ -112,7 +112,9 @@ int time_it(const char* name, int n, int reps, F&& launch) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  for (int i = 0; i < 5; ++i) launch();
+  // warm up as long as the timed part: the clock keeps rising over the first milliseconds of load, which
+  // would otherwise favour whichever variant is timed second
+  for (int i = 0; i < reps; ++i) launch();
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
   for (int i = 0; i < reps; ++i) launch();
@@ -131,6 +133,56 @@ int run_dma(const char* name, const GemmArgs<float>& g, int n, int reps) {
   const int lds = STAGES * 2 * BK * 64 * 4;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   return time_it(name, n, reps, [&] { hipLaunchKernelGGL(kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, 0, g); });
+}
+
+template <int RM, int RN, int RK, int RWM, int RWN, int ROCC, int BM, int BN, int BK, int WM, int WN, int OCC, int STAGES>
+int compare_tiles(const char* name, int n) {
+  float *a, *b, *c, *c_ref;
+  CHECK(hipMalloc(&a, sizeof(float) * n * n));
+  CHECK(hipMalloc(&b, sizeof(float) * n * n));
+  CHECK(hipMalloc(&c, sizeof(float) * n * n));
+  CHECK(hipMalloc(&c_ref, sizeof(float) * n * n));
+  std::vector<float> host(size_t(n) * n);
+  for (size_t i = 0; i < host.size(); ++i) host[i] = float((i * 2654435761u % 7000) / 1000.0 - 2.0);
+  CHECK(hipMemcpy(a, host.data(), sizeof(float) * n * n, hipMemcpyHostToDevice));
+  for (size_t i = 0; i < host.size(); ++i) host[i] = float((i * 40503u % 7000) / 1000.0 - 2.0);
+  CHECK(hipMemcpy(b, host.data(), sizeof(float) * n * n, hipMemcpyHostToDevice));
+  GemmArgs<float> g{};
+  g.a = a; g.b = b; g.c = c_ref;
+  g.m = g.n = g.k = n;
+  g.lda = g.ldb = g.ldc = n;
+  g.batch = 1; g.split_k = 1; g.k_chunk = n;
+  g.vec_a = g.vec_b = 1;
+  g.alpha = 1.0f; g.beta = 0.0f; g.beta_zero = 1;
+  const int reps = n >= 8192 ? 5 : n >= 4096 ? 20 : 100;
+  std::printf("DMA_LAB -- %s\n", name);
+  {
+    using K = GemmTile<float, RM, RN, RK, RWM, RWN, false, true>;
+    auto kernel = gemm_mfma_kernel<float, RM, RN, RK, RWM, RWN, false, true, ROCC>;
+    g.tiles_m = n / RM; g.tiles_n = n / RN;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(K::LDS_BYTES)));
+    if (time_it("register-staged", n, reps,
+                [&] { hipLaunchKernelGGL(kernel, dim3(g.tiles_m * g.tiles_n), dim3(K::NT), K::LDS_BYTES, 0, g); }))
+      return 1;
+  }
+  {
+    auto kernel = gemm_mfma_dma_kernel<BM, BN, BK, WM, WN, false, true, OCC, STAGES>;
+    const int lds = STAGES * (BM + BN) * BK * 4;
+    g.c = c;
+    g.tiles_m = n / BM; g.tiles_n = n / BN;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (time_it("direct-to-LDS", n, reps,
+                [&] { hipLaunchKernelGGL(kernel, dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, 0, g); }))
+      return 1;
+  }
+  std::vector<float> got(size_t(n) * n), want(size_t(n) * n);
+  CHECK(hipMemcpy(got.data(), c, sizeof(float) * n * n, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(want.data(), c_ref, sizeof(float) * n * n, hipMemcpyDeviceToHost));
+  size_t bad = 0;
+  for (size_t i = 0; i < got.size(); ++i) bad += got[i] != want[i];
+  std::printf("DMA_LAB    %zu of %zu elements differ\n", bad, got.size());
+  hipFree(a); hipFree(b); hipFree(c); hipFree(c_ref);
+  return 0;
 }
 
 int main() {
@@ -177,5 +229,13 @@ int main() {
     std::printf("DMA_LAB %d^3 (last variant): %zu of %zu elements differ from the library kernel\n", n, bad, got.size());
     hipFree(a); hipFree(b); hipFree(c); hipFree(c_ref);
   }
+  // the library's direct-to-LDS kernel on the bigger tiles against the register-staged kernel
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 32, 4, 2, 2, 3>("128x128x32 reg  vs 128x128x32 dma 3 stages", 2048)) return 1;
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 16, 4, 2, 2, 3>("128x128x32 reg  vs 128x128x16 dma 3 stages", 2048)) return 1;
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 16, 4, 2, 2, 4>("128x128x32 reg  vs 128x128x16 dma 4 stages", 4096)) return 1;
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 32, 4, 2, 2, 3>("128x128x32 reg  vs 128x128x32 dma 3 stages", 4096)) return 1;
+  if (compare_tiles<256, 256, 16, 4, 2, 2, 256, 256, 16, 4, 2, 2, 3>("256x256x16 reg  vs 256x256x16 dma 3 stages", 8192)) return 1;
+  if (compare_tiles<256, 256, 16, 4, 2, 2, 256, 256, 16, 4, 2, 2, 4>("256x256x16 reg  vs 256x256x16 dma 4 stages", 8192)) return 1;
+  if (compare_tiles<256, 256, 16, 4, 2, 2, 256, 256, 32, 4, 2, 2, 2>("256x256x16 reg  vs 256x256x32 dma 2 stages", 8192)) return 1;
   return 0;
 }
