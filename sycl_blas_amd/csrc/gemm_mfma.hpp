@@ -951,43 +951,49 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  static_assert(NGRP % 2 == 0, "the fragment double buffer must come back to slot 0");
+  float fa[2][MI][2], fb[2][NI][2];
+  auto fetch = [&](const SBAMD_LDS float* st, int grp, int slot) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) OpA::fragment(st, grp, a_mn + i * 32, lane, fa[slot][i]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) OpB::fragment(st + OpA::ELEMS, grp, b_mn + j * 32, lane, fb[slot][j]);
+  };
+  auto mma = [&](int slot) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = M::mma(fb[slot][j][e], fa[slot][i][e], acc[i][j]);
+  };
+  if (nk > 0) fetch(smem, 0, 0);
+
+  // One K step: the barrier sits in front of the LAST fragment group's matrix instructions.  By then
+  // every fragment of tile t is in registers (its stage is refilled at the top of the next step) and this
+  // wave's pieces of tile t + 1 have landed, so the first fragments of tile t + 1 are fetched behind the
+  // barrier and their latency hides under the last group's matrix instructions.
   int cur = 0, fill = STAGES - 1;
   for (int t = 0; t < nk; ++t) {
-    // the stage filled now was read during the previous step; every wave has passed that step's barrier
     const bool more = t + STAGES - 1 < nk;
     if (more) {
       oa.issue(smem + fill * STAGE, g.lda, wave);
       ob.issue(smem + fill * STAGE + OpA::ELEMS, g.ldb, wave);
     }
-    const SBAMD_LDS float* as = smem + cur * STAGE;
-    const SBAMD_LDS float* bs = as + OpA::ELEMS;
-    float fa[2][MI][2], fb[2][NI][2];
+    const SBAMD_LDS float* st = smem + cur * STAGE;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) OpA::fragment(as, 0, a_mn + i * 32, lane, fa[0][i]);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) OpB::fragment(bs, 0, b_mn + j * 32, lane, fb[0][j]);
-#pragma unroll
-    for (int grp = 0; grp < NGRP; ++grp) {
-      const int cu = grp & 1, nx = cu ^ 1;
-      if (grp + 1 < NGRP) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) OpA::fragment(as, grp + 1, a_mn + i * 32, lane, fa[nx][i]);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) OpB::fragment(bs, grp + 1, b_mn + j * 32, lane, fb[nx][j]);
-      }
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = M::mma(fb[cu][j][e], fa[cu][i][e], acc[i][j]);
+    for (int grp = 0; grp + 1 < NGRP; ++grp) {
+      fetch(st, grp + 1, (grp + 1) & 1);
+      mma(grp & 1);
     }
-    // this wave's pieces of tile t + 1 have landed; the newer tiles may stay in flight
-    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_FLIGHT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     cur = cur + 1 == STAGES ? 0 : cur + 1;
     fill = fill + 1 == STAGES ? 0 : fill + 1;
+    if (t + 1 < nk) fetch(smem + cur * STAGE, 0, 0);
+    mma((NGRP - 1) & 1);
   }
 
   const float alpha = g.alpha, beta = g.beta;
