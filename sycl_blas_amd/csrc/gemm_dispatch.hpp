@@ -89,9 +89,9 @@ hipError_t launch_dma_tile(GemmArgs<float> g, hipStream_t stream) {
 // Only with both operands M/N-contiguous (A 'n', B 't'): their linear [k][mn] image is read without bank
 // conflicts.  A K-contiguous operand can only be swizzled in 16-byte pieces, which leaves its fragment
 // reads two-way conflicted, and measured slower than the register-staged kernel with its padded rows
-// (1024^3 on 64x64 tiles: NT 30.1 -> 28.6 us, but NN 31.0 -> 32.0, TN 31.7 -> 34.2).  On the 128x128 and
+// (1024^3 on 64x64 tiles: NT 29.7 -> 27.1 us, but NN 31.0 -> 32.0, TN 31.7 -> 34.2).  On the 128x128 and
 // 256x256 tiles the register-staged pipeline with its pinned instruction interleave stays ahead by 1-3 %
-// (2048^3 NT: 145 us against 148), so only the 64x64 tile uses it.
+// (2048^3 NT: 139.8 us against 142.6), so only the 64x64 tile uses it.
 template <typename T>
 inline bool dma_ok(const GemmArgs<T>& g, bool ta, bool tb, int64_t k_span, int bk) {
   if constexpr (sizeof(T) != 4) return false;
