@@ -508,9 +508,15 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     gp.k_chunk = k_chunk;
     gp.slice_stride = slice;
     gp.beta_zero = 1;
-    e = plan.tile == TILE_256   ? launch_huge<T>(gp, p.ta, p.tb, h->stream)
-        : plan.tile == TILE_128 ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, Tiles<T>::LARGE_WM, 2, 2>(gp, p.ta, p.tb, h->stream)
-                                : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
+    bool slabs_dma = false;
+    if constexpr (sizeof(T) == 4) slabs_dma = plan.tile == TILE_64 && p.k % 32 == 0 && dma_ok(gp, p.ta, p.tb, k_chunk, 32);
+    if constexpr (sizeof(T) == 4) {
+      if (slabs_dma) e = launch_dma_tile<64, 64, 32, 2, 2, 3, 3>(gp, h->stream);
+    }
+    if (!slabs_dma)
+      e = plan.tile == TILE_256   ? launch_huge<T>(gp, p.ta, p.tb, h->stream)
+          : plan.tile == TILE_128 ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, Tiles<T>::LARGE_WM, 2, 2>(gp, p.ta, p.tb, h->stream)
+                                  : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
     if (e != hipSuccess) return e;
     const int64_t grid = ceil_div(slice, 256);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)grid), dim3(256), 0, h->stream,
