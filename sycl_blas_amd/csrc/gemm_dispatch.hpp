@@ -365,9 +365,8 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
   // 28.9 -> 26.6 and 2048^3 fp32 156 -> 138, which the 10 % rule for K cuts turns down);
   // with more tiles it loses to the plain launch.
   for (int tile = TILE_64; tile <= TILE_128; ++tile) {
-    const int bk = tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
     const int edge = tile == TILE_128 ? 128 : 64, occ = tile == TILE_128 ? 2 : 4;
-    if (k % (2 * bk) != 0 || k < 512) continue;  // short K: the hand-over at the end is not free
+    if (k % (2 * Mfma<T>::V) != 0 || k < 512) continue;  // equal, vector-aligned halves; short K: the hand-over is not free
     if (ceil_div(m, edge) * ceil_div(n, edge) * 2 > int64_t(cus) * occ) continue;
     const double us = estimate_us<T>(tile, 2, m, n, k, 1, cus, true);
     if (us < 0.9 * best_us && us < chosen_us) chosen_us = us, chosen = {tile, 2, true};
@@ -485,7 +484,8 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   const int64_t k_chunk = std::max<int64_t>(bk, bk * ceil_div(p.k, int64_t(bk) * depth));
   depth = std::max<int64_t>(1, ceil_div(p.k, k_chunk));
 
-  if (depth == 2 && plan.fused && plan.tile != TILE_256 && p.k % (2 * bk) == 0) {
+  // equal halves whose start stays 16-byte aligned: both sets then run the same steps (and the same K tail)
+  if (depth == 2 && plan.fused && plan.tile != TILE_256 && p.k % (2 * Mfma<T>::V) == 0 && p.k / 2 >= bk) {
     GemmArgs<T> gp = g;
     gp.k_chunk = p.k / 2;
     hipError_t e = plan.tile == TILE_128

@@ -727,7 +727,8 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 // (splitk_reduce_kernel): the same result without the second launch and without
 // writing and re-reading the partial sums through HBM.  It doubles the wavefronts per
 // SIMD for shapes whose tiles alone leave the matrix pipes half idle (one 4-wave
-// workgroup per compute unit).  The host checks k % (2 * BK) == 0 and sets
+// workgroup per compute unit).  The host checks that k splits into two equal halves of at least one K step whose start stays
+// 16-byte aligned (both sets then run the same steps, K tail included) and sets
 // g.k_chunk = k / 2.
 template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC>
 __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)

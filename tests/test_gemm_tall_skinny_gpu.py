@@ -80,14 +80,16 @@ def test_two_halves_in_one_workgroup(sb_handle, tile, dtype):
     # steps falls back to the cube route.
     sb_handle.set_kernel(_lib.KERNEL_SPLITK, 2 | (tile << 16) | (1 << 24))
     try:
+        # the last two: halves that are not whole K steps (both sets then run the same K tail)
         for (m, n, k), ta, tb in itertools.product([(64, 64, 128), (128, 256, 512), (200, 130, 1024), (7, 9, 192),
-                                                    (257, 63, 640)], "nt", "nt"):
+                                                    (257, 63, 640), (200, 132, 1000), (64, 64, 136)], "nt", "nt"):
             for alpha, beta, ldm in ((1.5, 0.5, 1), (2.0, 0.0, 3)):
                 verify_gemm(sb_handle, dtype, 0, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
                 assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK
                 assert sb_handle.last_splitk() == (2, k // 2)
-        verify_gemm(sb_handle, dtype, 0, 1, 65, 126, 1000, "n", "t", 1.5, 0.5, 1, 1, 1)
-        assert sb_handle.last_splitk()[0] == 2
+        # a K whose halves would not start 16-byte aligned takes the cube route
+        verify_gemm(sb_handle, dtype, 0, 1, 65, 126, 1002, "n", "t", 1.5, 0.5, 1, 1, 1)
+        assert sb_handle.last_splitk()[0] == 2 and sb_handle.last_splitk()[1] != 501
     finally:
         sb_handle.set_kernel(_lib.KERNEL_AUTO)
 
