@@ -103,7 +103,10 @@ const char* sbamd_last_error(sbamd_handle_t h);
  * src/operations/blas3/gemm_partial_local.hpp:191-199 does), bits 16-23 = tile of
  * the partial products (0 = automatic, 1 = 64x64, 2 = 128x128, 3 = the biggest tile), bit 24 = keep
  * both halves of K (depth 2) inside one workgroup of the 64x64 / 128x128 tile instead of going through
- * the cube (same result as the cube route with two slabs; needs K to split into whole K steps). */
+ * the cube (same result as the cube route with two slabs; needs K to split into two equal halves whose
+ * start stays 16-byte aligned, else the cube route runs).
+ * SBAMD_KERNEL_SMALL: bit 0 = keep the register-staged kernel where the direct-to-LDS one would run
+ * (fp32, A 'n', B 't'; same bits either way -- a switch for A/B timing). */
 int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param);
 
 /* Which family the last GEMM call on this handle launched (SBAMD_KERNEL_*),
