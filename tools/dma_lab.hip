@@ -234,6 +234,11 @@ int main() {
     if (compare_tiles<64, 64, 32, 2, 2, 1, 64, 64, 32, 2, 2, 3, 3>("64x64x32 reg  vs 64x64x32 dma 3 stages", 1024)) return 1;
     if (compare_tiles<64, 64, 32, 2, 2, 1, 64, 64, 32, 2, 2, 3, 3>("64x64x32 reg  vs 64x64x32 dma 3 stages", 2048)) return 1;
   }
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 16, 2, 2, 2, 3>("128x128x32 reg (8 waves) vs 128x128x16 dma, 4 waves of 64x64", 2048)) return 1;
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 32, 2, 2, 1, 3>("128x128x32 reg (8 waves) vs 128x128x32 dma, 4 waves of 64x64", 2048)) return 1;
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 16, 2, 2, 2, 3>("128x128x32 reg (8 waves) vs 128x128x16 dma, 4 waves of 64x64", 4096)) return 1;
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 32, 2, 2, 1, 3>("128x128x32 reg (8 waves) vs 128x128x32 dma, 4 waves of 64x64", 4096)) return 1;
+  if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 16, 2, 4, 2, 3>("128x128x32 reg (8 waves) vs 128x128x16 dma, 8 waves of 64x32", 2048)) return 1;
   if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 32, 4, 2, 2, 3>("128x128x32 reg  vs 128x128x32 dma 3 stages", 2048)) return 1;
   if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 16, 4, 2, 2, 3>("128x128x32 reg  vs 128x128x16 dma 3 stages", 2048)) return 1;
   if (compare_tiles<128, 128, 32, 4, 2, 2, 128, 128, 16, 4, 2, 2, 4>("128x128x32 reg  vs 128x128x16 dma 4 stages", 4096)) return 1;
