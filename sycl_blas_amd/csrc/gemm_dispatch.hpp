@@ -95,7 +95,7 @@ hipError_t launch_dma_tile(GemmArgs<float> g, hipStream_t stream) {
 template <typename T>
 inline bool dma_ok(const GemmArgs<T>& g, bool ta, bool tb, int64_t k_span, int bk) {
   if constexpr (sizeof(T) != 4) return false;
-  return !ta && tb && g.vec_a && g.vec_b && k_span % bk == 0 && k_span >= 2 * bk && g.m % 4 == 0 && g.n % 4 == 0;
+  return !ta && tb && g.vec_a && g.vec_b && k_span >= 2 * bk && g.m % 4 == 0 && g.n % 4 == 0;
 }
 
 // Batches of one-tile, one-step items on a fixed set of workgroups (gemm_batch_stream_kernel).
@@ -509,7 +509,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     gp.slice_stride = slice;
     gp.beta_zero = 1;
     bool slabs_dma = false;
-    if constexpr (sizeof(T) == 4) slabs_dma = plan.tile == TILE_64 && p.k % 32 == 0 && dma_ok(gp, p.ta, p.tb, k_chunk, 32);
+    if constexpr (sizeof(T) == 4) slabs_dma = plan.tile == TILE_64 && p.k - (depth - 1) * k_chunk >= 64 && dma_ok(gp, p.ta, p.tb, k_chunk, 32);
     if constexpr (sizeof(T) == 4) {
       if (slabs_dma) e = launch_dma_tile<64, 64, 32, 2, 2, 3, 3>(gp, h->stream);
     }

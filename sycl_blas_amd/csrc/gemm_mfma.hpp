@@ -829,7 +829,7 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
 //                           position c ^ ((r >> 1) & (BK / 4 - 1)), chosen by WHICH piece each lane
 //                           fetches.  A fragment is the dword pair (k, k + 2) of one piece.
 // The matrix instructions, their order and the epilogue are those of gemm_mfma_kernel, so the two
-// kernels agree bit for bit.  The host checks: K a multiple of BK, 16-byte-loadable operands, and
+// kernels agree bit for bit.  The host checks: at least two whole K steps, 16-byte-loadable operands, and
 // no 16-byte vector straddling an edge (rows / vectors past the edge are clamped as above).
 typedef __attribute__((address_space(1))) const void* dma_src_t;
 typedef __attribute__((address_space(3))) void* dma_dst_t;
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     b += int64_t(z) * g.stride_b;
     c += int64_t(z) * g.stride_c;
   }
-  const int nk = int((k_end - k_begin) / BK);  // whole K steps (host)
+  const int nk = int((k_end - k_begin) / BK);  // whole K steps; the rest is the tail step at the end
 
   OpA oa;
   OpB ob;
@@ -995,6 +995,26 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     fill = fill + 1 == STAGES ? 0 : fill + 1;
     if (t + 1 < nk) fetch(smem + cur * STAGE, 0, 0);
     mma((NGRP - 1) & 1);
+  }
+
+  // K tail (< BK): one more step through registers.  The M/N-contiguous register-staged image is the same
+  // linear [k][mn] image, k past the end stored as exact zeros; every wave has passed the last barrier and no
+  // load is outstanding, so stage 0 is free.
+  const int64_t k_tail = k_begin + int64_t(nk) * BK;
+  if (k_tail < k_end) {
+    TileLoader<float, BM, BK, NWAVES * 64, false> ea;
+    TileLoader<float, BN, BK, NWAVES * 64, false> eb;
+    ea.load_edge(a, g.lda, m0, g.m, k_tail, k_end, tid);
+    eb.load_edge(b, g.ldb, n0, g.n, k_tail, k_end, tid);
+    ea.store(smem, tid);
+    eb.store(smem + OpA::ELEMS, tid);
+    __syncthreads();
+    fetch(smem, 0, 0);
+#pragma unroll
+    for (int grp = 0; grp < NGRP; ++grp) {
+      if (grp + 1 < NGRP) fetch(smem, grp + 1, (grp + 1) & 1);
+      mma(grp & 1);
+    }
   }
 
   const float alpha = g.alpha, beta = g.beta;

@@ -176,7 +176,7 @@ def test_cpp_symm_trsm_sample_through_compat_header():
 
 @pytest.mark.parametrize("offset", [0, 4])
 def test_operand_tiles_straight_into_lds(sb_handle, offset):
-    # fp32, A 'n' and B 't', K in whole steps of 32, 16-byte-loadable operands: the 64x64 tile stages its
+    # fp32, A 'n' and B 't', 16-byte-loadable operands: the 64x64 tile stages its
     # operands global -> LDS without registers.  Same matrix instructions in the same order as the
     # register-staged kernel: whole buffers equal the oracle bit for bit (verify_gemm), on interior tiles,
     # on tiles that hang over both edges, with padded leading dimensions, with and without reading C, for
@@ -184,10 +184,16 @@ def test_operand_tiles_straight_into_lds(sb_handle, offset):
     h = sb_handle
     h.set_kernel(_lib.KERNEL_SMALL)
     try:
-        for (m, n, k) in [(64, 64, 128), (128, 192, 160), (200, 132, 1024), (1024, 1024, 256), (68, 60, 96 + 32)]:
+        # the last three: K tails (one more step through registers after the streamed steps)
+        for (m, n, k) in [(64, 64, 128), (128, 192, 160), (200, 132, 1024), (1024, 1024, 256), (68, 60, 96 + 32),
+                          (200, 132, 1000), (128, 64, 129), (64, 128, 191)]:
             for alpha, beta, ldm in ((1.5, 0.5, 1), (2.0, 0.0, 3)):
                 verify_gemm(h, np.float32, offset, 1, m, n, k, "n", "t", alpha, beta, ldm, ldm, ldm)
                 assert h.last_kernel() == _lib.KERNEL_SMALL
         verify_gemm(h, np.float32, offset, 5, 128, 64, 256, "n", "t", 1.5, 0.5, 1, 1, 1)
+        # K slabs of a split on this tile take the same kernel (the last slab ends in a tail)
+        h.set_kernel(_lib.KERNEL_SPLITK, 3 | (1 << 16))
+        verify_gemm(h, np.float32, offset, 1, 256, 128, 1000, "n", "t", 1.5, 0.5, 1, 1, 1)
+        assert h.last_splitk()[0] == 3
     finally:
         h.set_kernel(_lib.KERNEL_AUTO)
