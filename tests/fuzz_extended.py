@@ -1,0 +1,57 @@
+"""Longer randomised walk than test_gemm_fuzz_gpu.py, biased towards the shapes the newer kernel paths take
+(vector-aligned M / N / K, every transpose, K with and without tails, forced K cuts).  Not collected by
+pytest; run by hand on a GPU box:  python tests/fuzz_extended.py [seed] [cases]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sycl_blas_amd as sb  # noqa: E402
+from sycl_blas_amd import _lib  # noqa: E402
+
+from common import verify_gemm, verify_gemm_strided  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+rng = np.random.default_rng(seed)
+with sb.SB_Handle(0) as h:
+    for i in range(cases):
+        dtype = np.float32 if rng.integers(0, 3) else np.float64
+        v = 16 // np.dtype(dtype).itemsize
+        m = int(rng.integers(1, 160)) * v if rng.integers(0, 4) else int(rng.integers(1, 600))
+        n = int(rng.integers(1, 160)) * v if rng.integers(0, 4) else int(rng.integers(1, 600))
+        k = int(rng.choice([int(rng.integers(1, 40)) * 32, int(rng.integers(1, 300)) * 2 * v, int(rng.integers(1, 3000))]))
+        ta, tb = str(rng.choice(["n", "t"])), str(rng.choice(["n", "t"]))
+        alpha = float(rng.choice([1.0, 1.5, -0.75]))
+        beta = float(rng.choice([0.0, 1.0, 0.5]))
+        ldm = int(rng.choice([1, 1, 2]))
+        offset = int(rng.choice([0, 0, v, 7]))
+        mode = int(rng.integers(0, 6))
+        if mode == 0:
+            h.set_kernel(_lib.KERNEL_SMALL)
+        elif mode == 1:
+            h.set_kernel(_lib.KERNEL_SPLITK, int(rng.choice([2, 3, 4, 5])) | (int(rng.integers(1, 4)) << 16) | (int(rng.integers(0, 2)) << 24))
+        else:
+            h.set_kernel(_lib.KERNEL_AUTO)
+        if mode == 5:
+            batch = int(rng.integers(2, 6))
+            verify_gemm(h, dtype, offset, batch, min(m, 200), min(n, 200), min(k, 400), ta, tb, alpha, beta, ldm, 1, 1)
+        else:
+            verify_gemm(h, dtype, offset, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
+        if i % 25 == 0:
+            print(f"case {i}: {np.dtype(dtype).name} {m}x{n}x{k} {ta}{tb} mode {mode} kernel {h.last_kernel()} cut {h.last_splitk()}", flush=True)
+    # long batches of single-tile items
+    h.set_kernel(_lib.KERNEL_AUTO)
+    for i in range(12):
+        dtype = np.float32 if rng.integers(0, 2) else np.float64
+        v = 16 // np.dtype(dtype).itemsize
+        m, n = int(rng.integers(1, 17)) * v, int(rng.integers(1, 17)) * v
+        m, n = min(m, 64), min(n, 64)
+        ta, tb = str(rng.choice(["n", "t"])), str(rng.choice(["n", "t"]))
+        batch = int(rng.integers(1030, 2400))
+        verify_gemm_strided(h, dtype, int(rng.choice([0, v])), batch, m, n, 64, ta, tb, 1.5, float(rng.choice([0.0, 0.5])),
+                            int(rng.choice([1, 2])), 1, int(rng.choice([1, 2])), int(rng.choice([0, 1, 2])), 1, int(rng.choice([1, 2])))
+        print(f"batch case {i}: {np.dtype(dtype).name} {m}x{n}x64 x{batch} {ta}{tb} kernel {h.last_kernel()}", flush=True)
+print("fuzz ok")
