@@ -356,6 +356,9 @@ int symm(sbamd_handle_t hh, char side, char uplo, int64_t m, int64_t n, T alpha,
          const T* b, int64_t ldb, T beta, T* c, int64_t ldc) {
   if (!hh) return SBAMD_INVALID_HANDLE;
   Handle* h = &hh->impl;
+  // scratch, the expansion kernel and the kernel attributes all belong to the handle's device
+  DeviceGuard guard(h->device);
+  if (!guard.ok) return SBAMD_HIP_ERROR;
   if (m < 0 || n < 0 || lda < 0 || ldb < 0 || ldc < 0) return SBAMD_INVALID_VALUE;
   side = char(std::tolower(static_cast<unsigned char>(side)));
   uplo = char(std::tolower(static_cast<unsigned char>(uplo)));
@@ -524,6 +527,8 @@ int trsm(sbamd_handle_t hh, char side, char uplo, char trans, char diag, int64_t
          int64_t lda, T* B, int64_t ldb) {
   if (!hh) return SBAMD_INVALID_HANDLE;
   Handle* h = &hh->impl;
+  DeviceGuard guard(h->device);
+  if (!guard.ok) return SBAMD_HIP_ERROR;
   if (M < 0 || N < 0 || lda < 0 || ldb < 0) return SBAMD_INVALID_VALUE;
   if (M == 0 || N == 0 || lda == 0 || ldb == 0) return SBAMD_TRSM_INVALID_SIZE;  // trsm_interface.hpp:114-116
   side = char(std::tolower(static_cast<unsigned char>(side)));

@@ -14,21 +14,45 @@ struct sbamd_event_s {
 
 namespace sbamd {
 
+// Frees the outgrown buffers whose last possible reader has finished
+// (`all`: the stream has been drained, free every one).  Caller holds h->mu.
+static void release_retired(Handle* h, bool all) {
+  size_t keep = 0;
+  for (size_t i = 0; i < h->retired.size(); ++i) {
+    Handle::Retired r = h->retired[i];
+    if (all || hipEventQuery(r.done) == hipSuccess) {
+      (void)hipEventDestroy(r.done);
+      (void)hipFree(r.ptr);
+    } else {
+      h->retired[keep++] = r;
+    }
+  }
+  h->retired.resize(keep);
+}
+
+// High-water-mark arena: a request that fits is served from what is there; a
+// bigger one gets a new allocation at once, and the old buffer -- which work
+// already queued on the stream may still read -- is parked with an event and
+// freed later.  The stream is never waited for here.
 static hipError_t grow(Handle* h, void** buf, size_t* have, size_t bytes) {
   std::lock_guard<std::mutex> lock(h->mu);
   if (bytes <= *have) return hipSuccess;
-  if (*buf) {
-    // Earlier work on the stream may still read the old buffer.
-    hipError_t e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) return e;
-    e = hipFree(*buf);
-    if (e != hipSuccess) return e;
-    *buf = nullptr;
-    *have = 0;
-  }
+  release_retired(h, false);
   const size_t rounded = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-  hipError_t e = hipMalloc(buf, rounded);
+  void* fresh = nullptr;
+  hipError_t e = hipMalloc(&fresh, rounded);
   if (e != hipSuccess) return e;
+  if (*buf) {
+    hipEvent_t done;
+    e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(done, h->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(fresh);
+      return e;
+    }
+    h->retired.push_back({*buf, done});
+  }
+  *buf = fresh;
   *have = rounded;
   return hipSuccess;
 }
@@ -42,19 +66,6 @@ int fail_hip(Handle* h, hipError_t e, const char* what) {
   h->last_error = std::string(what) + ": " + hipGetErrorString(e);
   return e == hipErrorOutOfMemory ? SBAMD_ALLOC_FAILED : SBAMD_HIP_ERROR;
 }
-
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = true;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-  }
-  ~DeviceGuard() {
-    int cur = -1;
-    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
-  }
-};
 
 // One policy per instantiated type pair (src/interface/blas3/gemm.cpp.in:33-137
 // plus bfloat16 -> float): storage types, the scalar type alpha/beta are held
@@ -290,6 +301,10 @@ int sbamd_destroy(sbamd_handle_t h) {
   if (!h) return SBAMD_INVALID_HANDLE;
   DeviceGuard guard(h->impl.device);
   (void)hipStreamSynchronize(h->impl.stream);
+  {
+    std::lock_guard<std::mutex> lock(h->impl.mu);
+    release_retired(&h->impl, true);
+  }
   if (h->impl.scratch) (void)hipFree(h->impl.scratch);
   if (h->impl.aux) (void)hipFree(h->impl.aux);
   if (h->impl.owns_stream) (void)hipStreamDestroy(h->impl.stream);
@@ -300,6 +315,11 @@ int sbamd_destroy(sbamd_handle_t h) {
 int sbamd_wait(sbamd_handle_t h) {
   if (!h) return SBAMD_INVALID_HANDLE;
   hipError_t e = hipStreamSynchronize(h->impl.stream);
+  if (e == hipSuccess && !h->impl.retired.empty()) {
+    DeviceGuard guard(h->impl.device);
+    std::lock_guard<std::mutex> lock(h->impl.mu);
+    release_retired(&h->impl, true);
+  }
   return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "stream synchronize");
 }
 
@@ -365,6 +385,7 @@ int sbamd_event_record(sbamd_handle_t h, sbamd_event_t* out) {
 int sbamd_stream_wait_event(sbamd_handle_t h, sbamd_event_t ev) {
   if (!h) return SBAMD_INVALID_HANDLE;
   if (!ev) return SBAMD_INVALID_VALUE;
+  DeviceGuard guard(h->impl.device);
   hipError_t e = hipStreamWaitEvent(h->impl.stream, ev->ev, 0);
   return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "stream wait event");
 }
@@ -399,8 +420,7 @@ int sbamd_free(sbamd_handle_t h, void* ptr) {
   if (!h) return SBAMD_INVALID_HANDLE;
   if (!ptr) return SBAMD_OK;
   DeviceGuard guard(h->impl.device);
-  (void)hipStreamSynchronize(h->impl.stream);
-  hipError_t e = hipFree(ptr);
+  hipError_t e = hipFree(ptr);  // waits for outstanding work on the device by itself
   return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "hipFree");
 }
 
@@ -408,6 +428,7 @@ int sbamd_copy_to_device(sbamd_handle_t h, void* dst_dev, const void* src_host, 
   if (!h) return SBAMD_INVALID_HANDLE;
   if (bytes == 0) return SBAMD_OK;
   if (!dst_dev || !src_host) return SBAMD_INVALID_VALUE;
+  DeviceGuard guard(h->impl.device);
   hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->impl.stream);
   return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "copy to device");
 }
@@ -416,6 +437,7 @@ int sbamd_copy_to_host(sbamd_handle_t h, void* dst_host, const void* src_dev, si
   if (!h) return SBAMD_INVALID_HANDLE;
   if (bytes == 0) return SBAMD_OK;
   if (!dst_host || !src_dev) return SBAMD_INVALID_VALUE;
+  DeviceGuard guard(h->impl.device);
   hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->impl.stream);
   return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "copy to host");
 }
@@ -424,6 +446,7 @@ int sbamd_memset(sbamd_handle_t h, void* dst_dev, int byte_value, size_t bytes) 
   if (!h) return SBAMD_INVALID_HANDLE;
   if (bytes == 0) return SBAMD_OK;
   if (!dst_dev) return SBAMD_INVALID_VALUE;
+  DeviceGuard guard(h->impl.device);
   hipError_t e = hipMemsetAsync(dst_dev, byte_value, bytes, h->impl.stream);
   return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "memset");
 }

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/sbamd_gemm.h"
 
@@ -36,8 +37,33 @@ struct Handle {
   // the cube because those drivers issue GEMM calls that may use the cube.
   void* aux = nullptr;
   size_t aux_bytes = 0;
+  // Buffers that were outgrown while work queued on the stream might still use
+  // them: each waits here with an event recorded at the moment it was replaced
+  // and is freed once that event has completed (no wait in the middle of a stream).
+  struct Retired {
+    void* ptr;
+    hipEvent_t done;
+  };
+  std::vector<Retired> retired;
   std::mutex mu;
   std::string last_error;
+};
+
+// Makes `dev` the current device for the lifetime of the object and restores
+// the previous one afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
 // A kernel attribute (the dynamic LDS limit) belongs to one device's copy of the
