@@ -51,7 +51,8 @@ enum {
   SBAMD_TRSM_INVALID_SIDE = 14,  /* "invalid Side argument"        trsm_interface.hpp:124 */
   SBAMD_TRSM_INVALID_UPLO = 15,  /* "invalid Triangle argument"    trsm_interface.hpp:126 */
   SBAMD_TRSM_INVALID_TRANS = 16, /* "invalid Transpose argument"   trsm_interface.hpp:128 */
-  SBAMD_TRSM_INVALID_DIAG = 17   /* "invalid Diagonal argument"    trsm_interface.hpp:130 */
+  SBAMD_TRSM_INVALID_DIAG = 17,  /* "invalid Diagonal argument"    trsm_interface.hpp:130 */
+  SBAMD_SCRATCH_TOO_SMALL = 18   /* sbamd_sgemm_noalloc only: the call's split-K cube exceeds the fixed array */
 };
 
 /* Batch layouts: include/operations/blas3_trees.h:59 (gemm_batch_type_t). */
@@ -191,6 +192,25 @@ int sbamd_hsgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t 
 int sbamd_bsgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
                  float alpha, const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb,
                  float beta, float* c, int64_t ldc);
+
+/* sbamd_sgemm for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
+ * no counterpart in the reference.  Same arguments, same kernels, same result
+ * bit for bit as sbamd_sgemm; the only difference is where a split-K call keeps
+ * its partial products: in a fixed array of SBAMD_NOALLOC_SCRATCH_BYTES that
+ * every GPU the library runs on holds until the process ends, instead of the
+ * handle's on-demand buffer.  The call makes no hipMalloc / hipFree.  A call
+ * whose cube (m * n * depth floats; sbamd_last_splitk reports depth) does not
+ * fit returns SBAMD_SCRATCH_TOO_SMALL and launches nothing.  All handles on one
+ * GPU share that GPU's array: calls through this entry point that overlap in
+ * time on one GPU (different streams or host threads) race on it; calls on one
+ * stream are ordered and safe.  Nothing in the array has to start at zero (every
+ * partial product is written before the reduction reads it), so it is never
+ * cleared and keeps the last call's contents. */
+#define SBAMD_NOALLOC_SCRATCH_BYTES ((size_t)64 << 20)
+int sbamd_sgemm_noalloc(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                        int64_t k, float alpha, const float* a, int64_t lda, const float* b,
+                        int64_t ldb, float beta, float* c, int64_t ldc);
 
 /* Replaces blas::_gemm_batched (blas3_interface.h:97-109).  For
  * SBAMD_BATCH_STRIDED the strides default to whole matrices

@@ -17,6 +17,8 @@ INVALID_TRANSA, INVALID_TRANSB, INVALID_STRIDEC, INVALID_STRIDEA, INVALID_STRIDE
 INVALID_HANDLE, INVALID_VALUE, HIP_ERROR, ALLOC_FAILED, NOT_SUPPORTED = 6, 7, 8, 9, 10
 INVALID_UPLO, INVALID_SIDE = 11, 12
 TRSM_INVALID_SIZE, TRSM_INVALID_SIDE, TRSM_INVALID_UPLO, TRSM_INVALID_TRANS, TRSM_INVALID_DIAG = 13, 14, 15, 16, 17
+SCRATCH_TOO_SMALL = 18
+NOALLOC_SCRATCH_BYTES = 64 << 20
 BATCH_STRIDED, BATCH_INTERLEAVED = 0, 1
 KERNEL_AUTO, KERNEL_LARGE, KERNEL_SMALL, KERNEL_SPLITK, KERNEL_NAIVE, KERNEL_HUGE = 0, 1, 2, 3, 4, 5
 KERNEL_INTERLEAVED = 6
@@ -64,6 +66,7 @@ SIGNATURES = {
     "sbamd_memset": (_int, [_vp, _vp, _int, C.c_size_t]),
     "sbamd_fill_uniform": (_int, [_vp, _vp, _i64, _int, C.c_uint64, _f64, _f64]),
     "sbamd_sgemm": (_int, _gemm_sig(_f32)),
+    "sbamd_sgemm_noalloc": (_int, _gemm_sig(_f32)),
     "sbamd_dgemm": (_int, _gemm_sig(_f64)),
     "sbamd_hgemm": (_int, _gemm_sig(_f32)),
     "sbamd_hsgemm": (_int, _gemm_sig(_f32)),

@@ -12,6 +12,14 @@ struct sbamd_event_s {
   hipEvent_t ev;
 };
 
+// Split-K cube of the entry point that allocates nothing (sbamd_sgemm_noalloc):
+// a fixed array in every GPU's memory, held from the moment the library's code
+// is loaded on that GPU until the process ends.  In host code the name is only
+// a stand-in for the symbol, never a device address: the address on a given GPU
+// comes from hipGetSymbolAddress with that GPU current (fixed_scratch_of below,
+// called from sbamd_create) and is what every kernel argument uses.
+static __device__ __align__(256) unsigned char scratch[SBAMD_NOALLOC_SCRATCH_BYTES];
+
 namespace sbamd {
 
 // Frees the outgrown buffers whose last possible reader has finished
@@ -37,6 +45,10 @@ static void release_retired(Handle* h, bool all) {
 static hipError_t grow(Handle* h, void** buf, size_t* have, size_t bytes) {
   std::lock_guard<std::mutex> lock(h->mu);
   if (bytes <= *have) return hipSuccess;
+  if (h->no_alloc) {
+    h->scratch_refused = true;
+    return hipErrorOutOfMemory;
+  }
   release_retired(h, false);
   const size_t rounded = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
   void* fresh = nullptr;
@@ -54,6 +66,24 @@ static hipError_t grow(Handle* h, void** buf, size_t* have, size_t bytes) {
   }
   *buf = fresh;
   *have = rounded;
+  return hipSuccess;
+}
+
+// The address of `scratch` on the current device, looked up once per device.
+static hipError_t fixed_scratch_of(int device, void** out) {
+  static std::mutex mu;
+  static void* per_device[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  if (device >= 0 && device < 64 && per_device[device]) {
+    *out = per_device[device];
+    return hipSuccess;
+  }
+  void* ptr = nullptr;
+  hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+  if (e != hipSuccess) return e;
+  if (!ptr) return hipErrorInvalidSymbol;
+  if (device >= 0 && device < 64) per_device[device] = ptr;
+  *out = ptr;
   return hipSuccess;
 }
 
@@ -219,6 +249,10 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   p.interleaved = batch_type == SBAMD_BATCH_INTERLEAVED && batch > 1;
   hipError_t e = P::run(h, p, alpha, beta);
   if (e == hipErrorNotSupported) return SBAMD_NOT_SUPPORTED;
+  if (h->no_alloc && h->scratch_refused) {
+    h->last_error = "the call needs more scratch than the fixed array of the no-allocation entry point holds";
+    return SBAMD_SCRATCH_TOO_SMALL;
+  }
   return e == hipSuccess ? SBAMD_OK : fail_hip(h, e, "gemm launch");
 }
 
@@ -265,6 +299,7 @@ const char* sbamd_status_string(int status) {
     case SBAMD_TRSM_INVALID_UPLO: return "invalid Triangle argument";
     case SBAMD_TRSM_INVALID_TRANS: return "invalid Transpose argument";
     case SBAMD_TRSM_INVALID_DIAG: return "invalid Diagonal argument";
+    case SBAMD_SCRATCH_TOO_SMALL: return "scratch demand exceeds the fixed array of the no-allocation entry point";
     default: return "unknown status";
   }
 }
@@ -284,6 +319,11 @@ int sbamd_create(sbamd_handle_t* out, int device, void* stream) {
     return SBAMD_HIP_ERROR;
   }
   h->impl.compute_units = prop.multiProcessorCount;
+  // this device's copy of the fixed scratch array (device `device` is current here)
+  if (fixed_scratch_of(device, &h->impl.fixed_scratch) != hipSuccess) {
+    delete h;
+    return SBAMD_HIP_ERROR;
+  }
   if (stream) {
     h->impl.stream = static_cast<hipStream_t>(stream);
   } else {
@@ -468,6 +508,28 @@ int sbamd_sgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n
   // blas::_gemm: strides 0, batch 1, strided (gemm_interface.hpp:194-197)
   return gemm_backend<PolicyS>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c,
                                     ldc, 0, 1, SBAMD_BATCH_STRIDED);
+}
+
+int sbamd_sgemm_noalloc(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
+                        float alpha, const float* a, int64_t lda, const float* b, int64_t ldb, float beta,
+                        float* c, int64_t ldc) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  Handle* hp = &h->impl;
+  if (!hp->fixed_scratch) return SBAMD_HIP_ERROR;
+  // For the length of this call the cube is the device's fixed array and the
+  // arena refuses to grow; the handle's own buffers are put back afterwards.
+  void* const saved = hp->scratch;
+  const size_t saved_bytes = hp->scratch_bytes;
+  hp->scratch = hp->fixed_scratch;
+  hp->scratch_bytes = SBAMD_NOALLOC_SCRATCH_BYTES;
+  hp->no_alloc = true;
+  hp->scratch_refused = false;
+  const int st = gemm_backend<PolicyS>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c, ldc, 0, 1,
+                                       SBAMD_BATCH_STRIDED);
+  hp->no_alloc = false;
+  hp->scratch = saved;
+  hp->scratch_bytes = saved_bytes;
+  return st;
 }
 
 int sbamd_dgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,

@@ -45,6 +45,12 @@ struct Handle {
     hipEvent_t done;
   };
   std::vector<Retired> retired;
+  // Set for the duration of a call through the entry point that allocates
+  // nothing: `scratch` then points at this device's fixed array and a request
+  // beyond its size is refused instead of served by hipMalloc.
+  bool no_alloc = false;
+  bool scratch_refused = false;
+  void* fixed_scratch = nullptr;  // this device's address of the fixed array
   std::mutex mu;
   std::string last_error;
 };
