@@ -65,8 +65,80 @@ inline bool vec16_ok(const uint16_t* p, int64_t ld, int64_t stride, int64_t batc
 }
 
 template <typename Tag, typename TOut>
+hipError_t launch16_interleaved(const GemmArgs16<TOut>& g, bool ta, bool tb, hipStream_t stream) {
+  constexpr int IR = 4, IC = 4;
+  const int64_t total = ceil_div(g.m, IR) * ceil_div(g.n, IC) * g.batch;
+  const int64_t grid = ceil_div(total, 256);
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (ta) {
+    if (tb) hipLaunchKernelGGL((gemm_interleaved16_kernel<Tag, TOut, true, true, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_interleaved16_kernel<Tag, TOut, true, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  } else {
+    if (tb) hipLaunchKernelGGL((gemm_interleaved16_kernel<Tag, TOut, false, true, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_interleaved16_kernel<Tag, TOut, false, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  }
+  return hipGetLastError();
+}
+
+template <typename Tag, typename TOut>
+hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float beta);
+
+// Interleaved batches (first branch of the reference's dispatch, amd_gpu.hpp:58-74; for half inputs
+// default.hpp:150-166).  Small items run with the batch index on the lanes; items with enough
+// arithmetic per repacked byte are turned into one column-major matrix per item in the handle's
+// second scratch area, run on the strided matrix-instruction kernels and written back.
+template <typename Tag, typename TOut>
+hipError_t run16_interleaved(Handle* h, const Problem<uint16_t, TOut>& p, const GemmArgs16<TOut>& g, float alpha,
+                             float beta) {
+  const double flops = 2.0 * double(p.m) * double(p.n) * double(p.k);
+  const double moved = 2.0 * (2.0 * (double(p.m) * double(p.k) + double(p.k) * double(p.n)) +
+                              sizeof(TOut) * (p.beta_zero ? 1.0 : 2.0) * double(p.m) * double(p.n));
+  const bool repack = p.m >= 32 && p.n >= 32 && flops >= 20.0 * moved;
+  if (!repack) {
+    h->last_kernel = SBAMD_KERNEL_INTERLEAVED;
+    return launch16_interleaved<Tag, TOut>(g, p.ta, p.tb, h->stream);
+  }
+  const int64_t a_rows = p.ta ? p.k : p.m, a_cols = p.ta ? p.m : p.k;
+  const int64_t b_rows = p.tb ? p.n : p.k, b_cols = p.tb ? p.k : p.n;
+  // packed leading dimensions padded to whole 16-byte vectors, so the strided kernels take their fast path
+  const int64_t lda = ceil_div(a_rows, 8) * 8, ldb = ceil_div(b_rows, 8) * 8, ldc = ceil_div(p.m, 8) * 8;
+  const int64_t na = lda * a_cols, nb = ldb * b_cols, nc = ldc * p.n;
+  const size_t bytes_ab = size_t(na + nb) * size_t(p.batch) * 2;
+  const size_t off_c = (bytes_ab + 255) & ~size_t(255);
+  hipError_t e = ensure_aux(h, off_c + size_t(nc) * size_t(p.batch) * sizeof(TOut));
+  if (e != hipSuccess) return e;
+  uint16_t* pa = static_cast<uint16_t*>(h->aux);
+  uint16_t* pb = pa + na * p.batch;
+  TOut* pc = reinterpret_cast<TOut*>(static_cast<unsigned char*>(h->aux) + off_c);
+  // the padding rows of the packed operands feed nothing (rows past m / k are never read as operands)
+  auto to_packed = [&](auto* inter, auto* packed, int64_t rows, int64_t cols, int64_t ld_inter, int64_t ld_packed) {
+    using E = std::remove_cv_t<std::remove_pointer_t<decltype(packed)>>;
+    // one launch per column block keeps the kernel's packed stride = rows: repack into a rows x cols
+    // image first when no padding is needed, else column by column through the padded stride
+    const int64_t grid = ceil_div(rows, 32) * ceil_div(p.batch, 32) * cols;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((repack_interleaved_ld_kernel<E, true>), dim3((unsigned)grid), dim3(256), 0, h->stream,
+                       const_cast<E*>(inter), packed, rows, cols, ld_inter, ld_packed, p.batch);
+    return hipGetLastError();
+  };
+  if ((e = to_packed(p.a, pa, a_rows, a_cols, p.lda, lda)) != hipSuccess) return e;
+  if ((e = to_packed(p.b, pb, b_rows, b_cols, p.ldb, ldb)) != hipSuccess) return e;
+  if (!p.beta_zero && (e = to_packed(p.c, pc, p.m, p.n, p.ldc, ldc)) != hipSuccess) return e;
+  Problem<uint16_t, TOut> q = p;
+  q.interleaved = false;
+  q.a = pa, q.lda = lda, q.stride_a = na;
+  q.b = pb, q.ldb = ldb, q.stride_b = nb;
+  q.c = pc, q.ldc = ldc, q.stride_c = nc;
+  if ((e = run16<Tag, TOut>(h, q, alpha, beta)) != hipSuccess) return e;
+  const int64_t grid = ceil_div(p.m, 32) * ceil_div(p.batch, 32) * p.n;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((repack_interleaved_ld_kernel<TOut, false>), dim3((unsigned)grid), dim3(256), 0, h->stream, p.c, pc,
+                     p.m, p.n, p.ldc, ldc, p.batch);
+  return hipGetLastError();
+}
+
+template <typename Tag, typename TOut>
 hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float beta) {
-  if (p.interleaved) return hipErrorNotSupported;
   GemmArgs16<TOut> g;
   g.a = p.a;
   g.b = p.b;
@@ -90,6 +162,7 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
   g.split_k = 1;
   g.k_chunk = p.k;
   g.slice_stride = 0;
+  if (p.interleaved) return run16_interleaved<Tag, TOut>(h, p, g, alpha, beta);
 
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
   // The direct-to-LDS 256x256 kernel needs whole K steps, 16-byte vectors and no

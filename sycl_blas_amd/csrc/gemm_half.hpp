@@ -315,6 +315,85 @@ __global__ void __launch_bounds__(256)
   store_out(p, sum);
 }
 
+// Storage bits -> float (exact for both formats).
+__device__ inline float widen(HalfTag, uint16_t v) { return float(__builtin_bit_cast(_Float16, v)); }
+__device__ inline float widen(Bf16Tag, uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+
+// Interleaved batches of 16-bit items: element (r, c) of item b at (r + c*ld)*batch + b
+// (test/unittest/blas3/blas3_gemm_common.hpp:54-69).  Same structure as the fp32 / fp64
+// gemm_interleaved_kernel -- consecutive lanes take consecutive items, an IR x IC register
+// block of C per lane, no LDS (src/operations/blas3/gemm_interleaved.hpp:104-537) -- with
+// both operands widened to float before the fused multiply-add, the mixed-precision rule of
+// src/operations/blas3/gemm_common.hpp:53-59, and k walked in increasing order: every C
+// element is the fp32 chain of the widened inputs, rounded once to the output type.
+template <typename Tag, typename TOut, bool TA, bool TB, int IR, int IC>
+__global__ void __launch_bounds__(256) gemm_interleaved16_kernel(const GemmArgs16<TOut> g) {
+  const int64_t nb = g.batch;
+  const int64_t tiles_r = (g.m + IR - 1) / IR;
+  const int64_t tiles_c = (g.n + IC - 1) / IC;
+  const int64_t gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= nb * tiles_r * tiles_c) return;
+  const int64_t b = gid % nb;
+  const int64_t t = gid / nb;
+  const int64_t r0 = (t % tiles_r) * IR;
+  const int64_t c0 = (t / tiles_r) * IC;
+
+  float acc[IR][IC];
+#pragma unroll
+  for (int i = 0; i < IR; ++i)
+#pragma unroll
+    for (int j = 0; j < IC; ++j) acc[i][j] = 0.0f;
+
+  // clamped rows / columns only feed C elements that are never stored
+  const uint16_t* pa[IR];
+  const uint16_t* pb[IC];
+#pragma unroll
+  for (int i = 0; i < IR; ++i) {
+    const int64_t r = r0 + i < g.m ? r0 + i : g.m - 1;
+    pa[i] = g.a + (TA ? r * g.lda : r) * nb + b;
+  }
+#pragma unroll
+  for (int j = 0; j < IC; ++j) {
+    const int64_t c = c0 + j < g.n ? c0 + j : g.n - 1;
+    pb[j] = g.b + (TB ? c : c * g.ldb) * nb + b;
+  }
+  const int64_t step_a = (TA ? int64_t(1) : g.lda) * nb;
+  const int64_t step_b = (TB ? g.ldb : int64_t(1)) * nb;
+  for (int64_t k = 0; k < g.k; ++k) {
+    float av[IR], bv[IC];
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      av[i] = widen(Tag{}, *pa[i]);
+      pa[i] += step_a;
+    }
+#pragma unroll
+    for (int j = 0; j < IC; ++j) {
+      bv[j] = widen(Tag{}, *pb[j]);
+      pb[j] += step_b;
+    }
+#pragma unroll
+    for (int i = 0; i < IR; ++i)
+#pragma unroll
+      for (int j = 0; j < IC; ++j) acc[i][j] = __builtin_fmaf(av[i], bv[j], acc[i][j]);
+  }
+
+#pragma unroll
+  for (int j = 0; j < IC; ++j) {
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      if (r0 + i < g.m && c0 + j < g.n) {
+        TOut* p = g.c + ((r0 + i) + (c0 + j) * g.ldc) * nb + b;
+        float out = g.alpha * acc[i][j];
+        if (!g.beta_zero) {
+          const float bc = g.beta * load_out(p);
+          out = out + bc;
+        }
+        store_out(p, out);
+      }
+    }
+  }
+}
+
 // C = beta * C for 16-bit output (alpha == 0 path): multiply in fp32, round once.
 __global__ void __launch_bounds__(256)
     scale_matrix16_kernel(uint16_t* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride, int64_t batch,
