@@ -107,7 +107,7 @@ class SB_Handle {
  public:
   using event_t = std::vector<Event>;
 
-  explicit SB_Handle(int device = 0, void* hip_stream = nullptr) {
+  explicit SB_Handle(int device = 0, void* hip_stream = nullptr) : device_(device) {
     detail::check(sbamd_create(&h_, device, hip_stream));
   }
   ~SB_Handle() {
@@ -140,6 +140,7 @@ class SB_Handle {
     return s;
   }
   sbamd_handle_t native() const { return h_; }
+  int device() const { return device_; }
 
   // helpers used by the entry points below
   void depends_on(const event_t& deps) {
@@ -154,14 +155,17 @@ class SB_Handle {
 
  private:
   sbamd_handle_t h_ = nullptr;
+  int device_ = 0;
 };
 
 template <typename T>
 BufferIterator<T> make_sycl_iterator_buffer(SB_Handle& sb_handle, size_t count) {
   void* raw = nullptr;
   detail::check(sbamd_malloc(sb_handle.native(), &raw, count * sizeof(T)), sb_handle.native());
-  sbamd_handle_t h = sb_handle.native();  // the handle must outlive its buffers
-  std::shared_ptr<void> owner(raw, [h](void* p) { sbamd_free(h, p); });
+  // The deleter knows the device, not the handle: like the reference's BufferIterator, whose
+  // sycl::buffer lives on independently of the SB_Handle, a buffer may outlive the handle.
+  const int device = sb_handle.device();
+  std::shared_ptr<void> owner(raw, [device](void* p) { sbamd_device_free(device, p); });
   return BufferIterator<T>(owner, static_cast<T*>(raw));
 }
 
@@ -244,15 +248,6 @@ struct abi<double, double> {
     return sbamd_dgemm_batched(h, ta, tb, m, n, k, al, a, lda, b, ldb, be, c, ldc, batch, bt);
   }
 };
-// 16-bit inputs: no *_batched symbol; default strides as gemm_interface.hpp:213-219
-template <typename TIn, typename TOut, typename Fn>
-int batched16(Fn strided, sbamd_handle_t h, char ta, char tb, int64_t m, int64_t n, int64_t k, float al, const TIn* a,
-              int64_t lda, const TIn* b, int64_t ldb, float be, TOut* c, int64_t ldc, int64_t batch, int bt) {
-  if (bt != SBAMD_BATCH_STRIDED) return SBAMD_NOT_SUPPORTED;
-  const bool tra = (ta | 0x20) != 'n', trb = (tb | 0x20) != 'n';
-  return strided(h, ta, tb, m, n, k, al, a, lda, (tra ? m : k) * lda, b, ldb, (trb ? k : n) * ldb, be, c, ldc,
-                 ldc * n, batch);
-}
 #define SBAMD_ABI16(TIN, TOUT, PFX, COUT)                                                                         \
   template <>                                                                                                     \
   struct abi<TIN, TOUT> {                                                                                         \
@@ -272,7 +267,9 @@ int batched16(Fn strided, sbamd_handle_t h, char ta, char tb, int64_t m, int64_t
     static int batched(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t n, int64_t k, float al,             \
                        const TIN* a, int64_t lda, const TIN* b, int64_t ldb, float be, TOUT* c, int64_t ldc,      \
                        int64_t batch, int bt) {                                                                   \
-      return batched16<TIN, TOUT>(strided, h, ta, tb, m, n, k, al, a, lda, b, ldb, be, c, ldc, batch, bt);        \
+      return PFX##gemm_batched(h, ta, tb, m, n, k, al, reinterpret_cast<const uint16_t*>(a), lda,                 \
+                               reinterpret_cast<const uint16_t*>(b), ldb, be, reinterpret_cast<COUT*>(c), ldc,    \
+                               batch, bt);                                                                        \
     }                                                                                                             \
   };
 SBAMD_ABI16(half_t, half_t, sbamd_h, uint16_t)

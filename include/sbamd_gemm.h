@@ -148,6 +148,10 @@ int sbamd_event_destroy(sbamd_event_t ev);
  * handle's stream; sbamd_wait() or an event makes them visible. */
 int sbamd_malloc(sbamd_handle_t h, void** out, size_t bytes);
 int sbamd_free(sbamd_handle_t h, void* ptr);
+/* The same release without a handle (waits for the device's outstanding work, then frees):
+ * for owners that may outlive the handle they were allocated through, as a sycl::buffer
+ * outlives the SB_Handle in the reference (include/container/sycl_iterator.h:179-181). */
+int sbamd_device_free(int device, void* ptr);
 int sbamd_copy_to_device(sbamd_handle_t h, void* dst_dev, const void* src_host, size_t bytes);
 int sbamd_copy_to_host(sbamd_handle_t h, void* dst_host, const void* src_dev, size_t bytes);
 int sbamd_memset(sbamd_handle_t h, void* dst_dev, int byte_value, size_t bytes);
@@ -225,6 +229,22 @@ int sbamd_dgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, i
                         int64_t k, double alpha, const double* a, int64_t lda, const double* b,
                         int64_t ldb, double beta, double* c, int64_t ldc, int64_t batch,
                         int batch_type);
+
+/* The 16-bit pairs of blas::_gemm_batched (instantiated for every type pair incl. half:
+ * src/interface/blas3/gemm.cpp.in:56-79; half dispatch src/interface/blas3/backend/default.hpp:150-199),
+ * plus bfloat16 -> float.  Both batch layouts. */
+int sbamd_hgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                        int64_t k, float alpha, const uint16_t* a, int64_t lda, const uint16_t* b,
+                        int64_t ldb, float beta, uint16_t* c, int64_t ldc, int64_t batch,
+                        int batch_type);
+int sbamd_hsgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                         int64_t k, float alpha, const uint16_t* a, int64_t lda, const uint16_t* b,
+                         int64_t ldb, float beta, float* c, int64_t ldc, int64_t batch,
+                         int batch_type);
+int sbamd_bsgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n,
+                         int64_t k, float alpha, const uint16_t* a, int64_t lda, const uint16_t* b,
+                         int64_t ldb, float beta, float* c, int64_t ldc, int64_t batch,
+                         int batch_type);
 
 /* Replaces blas::_gemm_strided_batched (blas3_interface.h:111-123).  Item b
  * uses A + b*stride_a, B + b*stride_b, C + b*stride_c.  For batch > 1:

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sbamd_event_destroy": (_int, [_vp]),
     "sbamd_malloc": (_int, [_vp, C.POINTER(_vp), C.c_size_t]),
     "sbamd_free": (_int, [_vp, _vp]),
+    "sbamd_device_free": (_int, [_int, _vp]),
     "sbamd_copy_to_device": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "sbamd_copy_to_host": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "sbamd_memset": (_int, [_vp, _vp, _int, C.c_size_t]),
@@ -73,6 +74,9 @@ SIGNATURES = {
     "sbamd_bsgemm": (_int, _gemm_sig(_f32)),
     "sbamd_sgemm_batched": (_int, _gemm_batched_sig(_f32)),
     "sbamd_dgemm_batched": (_int, _gemm_batched_sig(_f64)),
+    "sbamd_hgemm_batched": (_int, _gemm_batched_sig(_f32)),
+    "sbamd_hsgemm_batched": (_int, _gemm_batched_sig(_f32)),
+    "sbamd_bsgemm_batched": (_int, _gemm_batched_sig(_f32)),
     "sbamd_sgemm_strided_batched": (_int, _gemm_strided_sig(_f32)),
     "sbamd_dgemm_strided_batched": (_int, _gemm_strided_sig(_f64)),
     "sbamd_hgemm_strided_batched": (_int, _gemm_strided_sig(_f32)),

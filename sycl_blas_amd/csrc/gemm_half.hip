@@ -93,7 +93,7 @@ hipError_t run16_interleaved(Handle* h, const Problem<uint16_t, TOut>& p, const 
   const double flops = 2.0 * double(p.m) * double(p.n) * double(p.k);
   const double moved = 2.0 * (2.0 * (double(p.m) * double(p.k) + double(p.k) * double(p.n)) +
                               sizeof(TOut) * (p.beta_zero ? 1.0 : 2.0) * double(p.m) * double(p.n));
-  const bool repack = p.m >= 32 && p.n >= 32 && flops >= 20.0 * moved;
+  const bool repack = p.m >= 32 && p.n >= 32 && flops >= 10.0 * moved;
   if (!repack) {
     h->last_kernel = SBAMD_KERNEL_INTERLEAVED;
     return launch16_interleaved<Tag, TOut>(g, p.ta, p.tb, h->stream);
@@ -113,8 +113,6 @@ hipError_t run16_interleaved(Handle* h, const Problem<uint16_t, TOut>& p, const 
   // the padding rows of the packed operands feed nothing (rows past m / k are never read as operands)
   auto to_packed = [&](auto* inter, auto* packed, int64_t rows, int64_t cols, int64_t ld_inter, int64_t ld_packed) {
     using E = std::remove_cv_t<std::remove_pointer_t<decltype(packed)>>;
-    // one launch per column block keeps the kernel's packed stride = rows: repack into a rows x cols
-    // image first when no padding is needed, else column by column through the padded stride
     const int64_t grid = ceil_div(rows, 32) * ceil_div(p.batch, 32) * cols;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((repack_interleaved_ld_kernel<E, true>), dim3((unsigned)grid), dim3(256), 0, h->stream,

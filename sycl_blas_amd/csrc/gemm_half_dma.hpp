@@ -148,7 +148,10 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  // the wavefront's index is uniform: kept in a scalar register, so is everything derived from it
+  // (the LDS destination of each load piece reaches M0 without a detour through vector registers:
+  // 69 -> 24 vector instructions beside the 80 matrix instructions of one trip of the main loop)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
 
   const int ntiles = g.tiles_m * g.tiles_n;

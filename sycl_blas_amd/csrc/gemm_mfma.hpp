@@ -1448,6 +1448,51 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same repacking with a padded packed image: element (r, c) of item b at
+// b*ld_packed*cols + r + c*ld_packed (ld_packed >= rows), so that every packed column starts
+// on a 16-byte boundary whatever `rows` is.  Rows between `rows` and ld_packed are never
+// written and never read as operands.
+template <typename T, bool TO_PACKED>
+__global__ void __launch_bounds__(256)
+    repack_interleaved_ld_kernel(T* __restrict__ inter, T* __restrict__ packed, int64_t rows, int64_t cols, int64_t ld,
+                                 int64_t ld_packed, int64_t batch) {
+  __shared__ T tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads
+  const int64_t tiles_r = (rows + 31) / 32, tiles_b = (batch + 31) / 32;
+  int64_t t = blockIdx.x;
+  const int64_t tb = t % tiles_b;
+  t /= tiles_b;
+  const int64_t tr = t % tiles_r;
+  const int64_t c = t / tiles_r;
+  const int64_t r0 = tr * 32, b0 = tb * 32;
+  const int64_t item = ld_packed * cols;
+  if (TO_PACKED) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = r0 + ty + 8 * i, b = b0 + tx;  // lanes along the batch
+      if (r < rows && b < batch) tile[ty + 8 * i][tx] = inter[(r + c * ld) * batch + b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = r0 + tx, b = b0 + ty + 8 * i;  // lanes along the rows
+      if (r < rows && b < batch) packed[b * item + r + c * ld_packed] = tile[tx][ty + 8 * i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = r0 + tx, b = b0 + ty + 8 * i;
+      if (r < rows && b < batch) tile[tx][ty + 8 * i] = packed[b * item + r + c * ld_packed];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = r0 + ty + 8 * i, b = b0 + tx;
+      if (r < rows && b < batch) inter[(r + c * ld) * batch + b] = tile[ty + 8 * i][tx];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- C = beta*C
 // alpha == 0 path (src/interface/gemm_interface.hpp:112-139).  assign_zero is
 // the whole-vector _scal with a zero factor, which stores zeros

@@ -464,6 +464,13 @@ int sbamd_free(sbamd_handle_t h, void* ptr) {
   return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "hipFree");
 }
 
+int sbamd_device_free(int device, void* ptr) {
+  if (!ptr) return SBAMD_OK;
+  DeviceGuard guard(device);
+  if (!guard.ok) return SBAMD_HIP_ERROR;
+  return hipFree(ptr) == hipSuccess ? SBAMD_OK : SBAMD_HIP_ERROR;
+}
+
 int sbamd_copy_to_device(sbamd_handle_t h, void* dst_dev, const void* src_host, size_t bytes) {
   if (!h) return SBAMD_INVALID_HANDLE;
   if (bytes == 0) return SBAMD_OK;
@@ -594,6 +601,22 @@ int sbamd_bsgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t 
                  int64_t ldc) {
   return gemm_backend<PolicyBS>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c, ldc, 0, 1,
                                 SBAMD_BATCH_STRIDED);
+}
+int sbamd_hgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k, float alpha,
+                        const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, float beta, uint16_t* c,
+                        int64_t ldc, int64_t batch, int batch_type) {
+  return gemm_batched<PolicyH>(h, transa, transb, m, n, k, to_half_precision(alpha), a, lda, b, ldb,
+                               to_half_precision(beta), c, ldc, batch, batch_type);
+}
+int sbamd_hsgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k, float alpha,
+                         const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, float beta, float* c,
+                         int64_t ldc, int64_t batch, int batch_type) {
+  return gemm_batched<PolicyHS>(h, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, batch, batch_type);
+}
+int sbamd_bsgemm_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k, float alpha,
+                         const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, float beta, float* c,
+                         int64_t ldc, int64_t batch, int batch_type) {
+  return gemm_batched<PolicyBS>(h, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, batch, batch_type);
 }
 int sbamd_hgemm_strided_batched(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,
                                 float alpha, const uint16_t* a, int64_t lda, int64_t stride_a, const uint16_t* b,

@@ -133,8 +133,9 @@ class _Allocation(DeviceBuffer):
         self._handle = handle
 
     def free(self):
-        if self.ptr and self._handle._h:
-            _lib.load().sbamd_free(self._handle._h, self.ptr)
+        if self.ptr:
+            # by device, not by handle: the allocation may outlive the handle it came from
+            _lib.load().sbamd_device_free(self._handle.device, self.ptr)
         self.ptr = 0
 
     def __del__(self):
@@ -156,6 +157,7 @@ class SB_Handle:
             raise SbamdError("sbamd_create: " + _lib.status_string(st))
         self._h = raw
         self.device = int(device)
+        self._pin = []  # host arrays of uploads that may still be in flight
 
     def close(self):
         if self._h:
@@ -178,6 +180,7 @@ class SB_Handle:
     def wait(self, events=None):
         if events is None:
             _check(self, _lib.load().sbamd_wait(self._h))
+            self._pin = []  # the stream has drained: every queued upload has read its host array
             return
         if isinstance(events, Event):
             events = [events]
@@ -245,11 +248,16 @@ class helper:
         count = host.size if count is None else int(count)
         nbytes = count * buf.itemsize
         assert host.itemsize == buf.itemsize and host.size >= count
-        # keep the host array alive until the copy has run
-        sb_handle._pin = getattr(sb_handle, "_pin", [])
+        # keep the host array alive until the copy has run: the returned event carries it, and the
+        # handle holds it until its stream is next drained (SB_Handle.wait())
         sb_handle._pin.append(host)
+        if len(sb_handle._pin) > 64:
+            _check(sb_handle, _lib.load().sbamd_wait(sb_handle._h))
+            sb_handle._pin = [host]
         _check(sb_handle, _lib.load().sbamd_copy_to_device(sb_handle._h, buf.ptr, host.ctypes.data, nbytes))
-        return sb_handle.record_event()
+        ev = sb_handle.record_event()
+        ev._keep = host
+        return ev
 
     @staticmethod
     def copy_to_host(sb_handle, buf, host, count=None):
@@ -323,26 +331,9 @@ def _gemm_batched(sb_handle, _TransA, _TransB, _M, _N, _K, _alpha, a_, _lda, b_,
     """blas::_gemm_batched (include/interface/blas3_interface.h:97-109)."""
     prefix, scalar = _pick(a_, b_, _C)
     sb_handle.depends_on(_dependencies)
-    lib = _lib.load()
-    name = prefix + "gemm_batched"
-    if hasattr(lib, name) and name in _lib.SIGNATURES:
-        st = getattr(lib, name)(sb_handle._h, _ch(_TransA), _ch(_TransB), int(_M), int(_N), int(_K),
-                                scalar(_alpha), a_.ptr, int(_lda), b_.ptr, int(_ldb), scalar(_beta),
-                                _C.ptr, int(_ldc), int(batch_size), int(batch_type))
-    else:
-        # Storage types without a *_batched symbol: default strides as
-        # src/interface/gemm_interface.hpp:213-219, strided only.
-        if int(batch_type) != int(gemm_batch_type_t.strided):
-            raise NotImplementedError("interleaved batches exist for float and double only")
-        ta = _ch(_TransA).lower() != b"n"
-        tb = _ch(_TransB).lower() != b"n"
-        sa = (_M if ta else _K) * _lda
-        sb = (_K if tb else _N) * _ldb
-        sc = _ldc * _N
-        st = getattr(lib, prefix + "gemm_strided_batched")(
-            sb_handle._h, _ch(_TransA), _ch(_TransB), int(_M), int(_N), int(_K), scalar(_alpha), a_.ptr,
-            int(_lda), int(sa), b_.ptr, int(_ldb), int(sb), scalar(_beta), _C.ptr, int(_ldc), int(sc),
-            int(batch_size))
+    fn = getattr(_lib.load(), prefix + "gemm_batched")
+    st = fn(sb_handle._h, _ch(_TransA), _ch(_TransB), int(_M), int(_N), int(_K), scalar(_alpha), a_.ptr, int(_lda),
+            b_.ptr, int(_ldb), scalar(_beta), _C.ptr, int(_ldc), int(batch_size), int(batch_type))
     _check(sb_handle, st)
     return [sb_handle.record_event()]
 

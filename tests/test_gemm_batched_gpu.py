@@ -135,3 +135,18 @@ def test_long_batches_of_single_tile_items(sb_handle, dtype):
     assert sb_handle.last_kernel() == _lib.KERNEL_SMALL
     verify_gemm_strided(sb_handle, dtype, 0, 1100, 64, 64, 48, "n", "n", 1.0, 0.0, 1, 1, 1, 1, 1, 1)
     assert sb_handle.last_kernel() == _lib.KERNEL_SMALL
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_interleaved_alpha_zero_scales_every_item_once(sb_handle, dtype):
+    # alpha == 0 on an interleaved batch: every item's m x n window is multiplied by beta once, the
+    # padding rows and the other buffers are untouched (verify_gemm compares the whole buffer with the
+    # oracle's per-item scaling).  A deliberate difference: the reference has no interleaved branch in
+    # its alpha == 0 shortcut (src/interface/gemm_interface.hpp:112-139) -- _gemm_batched passes
+    # _stridec = 0 for that layout (:209-220), so it scales the strided-addressed m x n window at C
+    # `batch` times and leaves the other items as they were; its tests only cover alpha == 0 with the
+    # strided layout (test/unittest/blas3/blas3_gemm_batched_test.cpp:68-104).
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    for beta, off, ldm in ((7.0, 0, 1), (0.0, 33, 4), (1.0, 0, 2)):
+        verify_gemm(sb_handle, dtype, off, 5, 63, 17, 9, "n", "t", 0.0, beta, 2, 3, ldm, batch_type=interleaved)
+        assert sb_handle.last_kernel() == -1  # no GEMM kernel ran
