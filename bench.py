@@ -10,16 +10,20 @@ on operands that are already resident in HBM.  Inputs are uniform in [-2, 5]
 generator with fixed seeds.
 
 N = 1: the workload is BASELINE config #2, SGEMM 8192 x 8192 x 8192 NN.
-N > 1: one process per GPU (launched by torch.distributed.run).  The GPUs form a
-Pr x Pc grid of C blocks; rank (i, j) owns the C block (i, j) and holds the A
-row-panel i and the B column-panel j, so the inner loop exchanges nothing.
-  --mode weak   (default) every rank's block is a full 8192^3 product: the job is a
-                (Pr*8192) x (Pc*8192) x 8192 GEMM, per-GPU work fixed.
-  --mode strong the job is one 8192^3 GEMM cut into Pr x Pc blocks.
-  --gather      additionally assemble C on every rank with an RCCL all-gather
-                inside the timed region.
-Rank 0 prints ONE JSON line.  `value` is whole-job TFLOP/s = 2*M*N*K summed over
-ranks / max-over-ranks wall time of the K timed steps.
+N > 1: one process per GPU (launched by torch.distributed.run), operands resident on
+every GPU.
+  --mode strong (default) the job is ONE 8192^3 GEMM whose full column-major C ends up
+                on every GPU, inside the timed region: the columns of C are dealt to
+                the ranks band by band, each rank multiplies straight into its slot
+                of the full C, and band b's RCCL all-gather (in place, no re-layout)
+                runs on a second stream while band b + 1 is being multiplied
+                (sycl_blas_amd.distributed.gathered_gemm).  --bands overrides the
+                number of bands, --no-gather leaves C distributed.
+  --mode weak   every rank multiplies a full 8192^3 block of a (Pr*8192) x (Pc*8192) x 8192
+                job (2-D C blocks, no exchange at all); also reported as an extra of
+                the strong run, never as its `value`.
+Rank 0 prints ONE JSON line.  `value` is whole-job TFLOP/s = 2*M*N*K of the job /
+max-over-ranks wall time of the K timed steps.
 """
 import argparse
 import json
@@ -47,8 +51,10 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--trans", choices=["nn", "nt", "tn", "tt"], default="nn")
     ap.add_argument("--size", type=int, default=8192)
-    ap.add_argument("--mode", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--gather", action="store_true")
+    ap.add_argument("--mode", choices=["weak", "strong"], default="strong")
+    ap.add_argument("--no-gather", action="store_true", help="strong mode: leave C distributed (no collective)")
+    ap.add_argument("--gather", action="store_true", help="accepted for compatibility: gathering is the default")
+    ap.add_argument("--bands", type=int, default=0, help="column bands of the overlapped gather (0 = choose)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--rehearse", action="store_true",
@@ -250,6 +256,51 @@ def load_traffic(dtype, trans, size):
         return None
 
 
+class StagedGather:
+    """--rehearse only: gloo cannot gather GPU tensors, so stage the collective through the host.
+    Same call shape as torch.distributed for what gathered_gemm uses."""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        self.torch.cuda.current_stream().synchronize()
+        host_out = self.torch.empty(out.numel(), dtype=out.dtype)
+        self.dist.all_gather_into_tensor(host_out, inp.cpu().contiguous(), group=group)
+        out.copy_(host_out)
+        return None
+
+
+def timed_steps(torch, dist, world, step, steps, handle=None, events=None):
+    """EXACTLY `steps` steps between a barrier + device synchronisation on both sides; seconds on this rank.
+    With `handle` and `events`, a HIP event is recorded on the handle's stream right before the first and right
+    after the last step (device time of the same region)."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if events is not None:
+        events.append(handle.record_event())
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if events is not None:
+        events.append(handle.record_event())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(torch, dist, world, seconds, on_cpu):
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     args = parse()
     import torch
@@ -273,58 +324,139 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import sycl_blas_amd as sb
-    from sycl_blas_amd.distributed import block_of, grid_for
+    from sycl_blas_amd.distributed import TorchStreams, block_of, gathered_gemm, grid_for, pick_bands
 
-    handle = sb.SB_Handle(local, torch.cuda.current_stream().cuda_stream)
+    # Everything of this rank -- allocations, fills, GEMMs -- is ordered on ONE explicit stream that
+    # torch and the library's handle share; collectives are launched from a second stream behind events.
+    compute = torch.cuda.Stream()
+    torch.cuda.set_stream(compute)
+    handle = sb.SB_Handle(local, compute.cuda_stream)
     ta, tb = args.trans[0], args.trans[1]
     size = args.size
     pr, pc = grid_for(world)
-    if args.mode == "weak":
-        gm, gn, gk = pr * size, pc * size, size
+    strong = world > 1 and args.mode == "strong"
+    gather = strong and not args.no_gather
+    comm = StagedGather(dist, torch) if args.rehearse else dist
+    extras = {}
+
+    if strong:
+        # ONE size^3 product; A, B (replicated, same seeds everywhere) and the full C live on every rank.
+        gm = gn = gk = size
+        ops = Operands(torch, sb, handle, args.dtype, ta, tb, gm, gn, gk, 12345)
+        bands = args.bands or pick_bands(world, gm, gn, gk)
+        if gn % (bands * world):
+            raise SystemExit(f"--size must be divisible by bands * ranks = {bands * world}")
+        streams = TorchStreams(torch, compute)
+        gemm_calls = []
+
+        def local_gemm(tra, trb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
+            gemm_calls.append((m, n, k))
+            sb._gemm(handle, tra, trb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc)
+
+        def own_columns_only():
+            # this rank's band multiplications with no collective behind them
+            w = gn // bands // world
+            for bi in range(bands):
+                col = bi * (gn // bands) + rank * w
+                local_gemm(ta, tb, gm, w, gk, 1.0, ops.a, ops.lda, ops.b + (col * ops.ldb if tb == "n" else col), ops.ldb, 0.0,
+                           ops.c + col * gm, gm)
+
+        def step():
+            if gather:
+                gathered_gemm(comm, local_gemm, rank, world, ta, tb, gm, gn, gk, 1.0, ops.a, ops.lda, ops.b, ops.ldb, 0.0,
+                              ops.c, ops.tc_t, bands=bands, streams=streams)
+            else:
+                own_columns_only()
+
+        bm, bn = gm, gn // world
     else:
-        gm, gn, gk = size, size, size
-    (r0, r1), (c0, c1) = block_of(rank, pr, pc, gm, gn)
-    bm, bn = r1 - r0, c1 - c0
-    ops = Operands(torch, sb, handle, args.dtype, ta, tb, bm, bn, gk, 12345 + 2 * rank)
+        if world > 1:  # weak: 2-D C blocks, every block a full size^3 product, nothing exchanged
+            gm, gn, gk = pr * size, pc * size, size
+        else:
+            gm, gn, gk = size, size, size
+        (r0, r1), (c0, c1) = block_of(rank, pr, pc, gm, gn)
+        bm, bn = r1 - r0, c1 - c0
+        ops = Operands(torch, sb, handle, args.dtype, ta, tb, bm, bn, gk, 12345 + 2 * rank)
+        bands = 1
 
-    gathered = None
-    if args.gather and world > 1:
-        gathered = torch.empty(world * bm * bn, dtype=ops.tc_t.dtype, device="cuda")
-
-    def step():
-        ops.run(sb, handle)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, ops.tc_t)
+        def step():
+            ops.run(sb, handle)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0 = handle.record_event()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ev1 = handle.record_event()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_ms(ev1) / args.steps  # device time per launch, events on the kernels' stream
-
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-
+    region = []
+    wall = timed_steps(torch, dist, world, step, args.steps, handle, region)
+    wall = max_over_ranks(torch, dist, world, wall, args.rehearse)
     flops_job = 2.0 * gm * gn * gk
     value = flops_job * args.steps / wall / 1e12
+
+    # Device time of this rank's multiplications alone (HIP events on the stream the kernels run on).
+    if strong:
+        shapes = list(dict.fromkeys(gemm_calls))
+
+        kernel_ms = device_time_ms(sb, handle, own_columns_only, max(3, args.steps // 2))
+        extras["strong"] = {"bands": bands, "band_gemm_shapes": shapes, "gemm_only_ms_per_step": round(kernel_ms, 4),
+                            "gather": gather}
+        if gather:
+            # the gather alone (all bands back to back, nothing to hide behind)
+            def gather_only():
+                works = []
+                width = gn // bands
+                for bi in range(bands):
+                    col = bi * width + rank * (width // world)
+                    out = ops.tc_t[bi * width * gm:(bi + 1) * width * gm]
+                    works.append(comm.all_gather_into_tensor(out, ops.tc_t[col * gm:(col + width // world) * gm],
+                                                             async_op=True))
+                for wk in works:
+                    if wk is not None:
+                        wk.wait()
+            for _ in range(2):
+                gather_only()
+            t_g = timed_steps(torch, dist, world, gather_only, max(3, args.steps // 2)) / max(3, args.steps // 2)
+            extras["strong"]["gather_only_ms_per_step"] = round(max_over_ranks(torch, dist, world, t_g, args.rehearse) * 1e3, 4)
+            # every rank must hold the same C, and a foreign part must equal this rank's own recomputation
+            # of it (same kernel, same shape: bit for bit)
+            step()
+            torch.cuda.synchronize()
+            digest = ops.tc_t.view(torch.int32 if args.dtype == "f32" else torch.int64).sum(dtype=torch.int64).reshape(1)
+            lo, hi = digest.clone(), digest.clone()
+            if args.rehearse:
+                lo, hi = lo.cpu(), hi.cpu()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            peer = (rank + 1) % world
+            w = gn // bands // world
+            col = peer * w  # the peer's part of band 0
+            theirs = ops.tc_t[col * gm:(col + w) * gm].clone()
+            sb._gemm(handle, ta, tb, gm, w, gk, 1.0, ops.a, ops.lda, ops.b + (col * ops.ldb if tb == "n" else col), ops.ldb, 0.0,
+                     ops.c + col * gm, gm)
+            torch.cuda.synchronize()
+            extras["strong"]["gathered_c_identical_on_all_ranks"] = bool(lo.item() == hi.item())
+            extras["strong"]["peer_part_equals_local_recompute"] = bool(torch.equal(theirs, ops.tc_t[col * gm:(col + w) * gm]))
+        # weak scaling, reported beside the headline, never as `value`
+        wops = Operands(torch, sb, handle, args.dtype, ta, tb, size, size, size, 999 + rank)
+        for _ in range(3):
+            wops.run(sb, handle)
+        t_w = timed_steps(torch, dist, world, lambda: wops.run(sb, handle), max(3, args.steps // 2)) / max(3, args.steps // 2)
+        t_w = max_over_ranks(torch, dist, world, t_w, args.rehearse)
+        extras["weak_no_exchange"] = {"job": f"{pr * size}x{pc * size}x{size}", "tflops": round(2.0 * size ** 3 * world / t_w / 1e12, 2),
+                                      "ms_per_step": round(t_w * 1e3, 4)}
+        del wops
+    else:
+        kernel_ms = region[0].elapsed_ms(region[1]) / args.steps  # device time per launch over the timed region itself
 
     if rank == 0:
         achieved = 2.0 * bm * bn * gk / (kernel_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        sd = "s" if args.dtype == "f32" else "d"
+        if strong:
+            workload = (f"{sd.upper()}GEMM {size}x{size}x{size} {args.trans.upper()} cut over {world} GPUs (columns of C dealt in {bands} "
+                        f"band(s)), alpha=1 beta=0, through sbamd_{sd}gemm" +
+                        (", full C gathered on every GPU inside the timed region (RCCL all-gather per band, overlapped)" if gather
+                         else ", C left distributed"))
+        else:
+            workload = (f"{sd.upper()}GEMM {size}x{size}x{size} {args.trans.upper()} per GPU C-block, alpha=1 beta=0, "
+                        f"through sbamd_{sd}gemm")
         out = {
             "metric": "SGEMM/DGEMM TFLOP/s at 8192^3 + % of MI355X MFMA peak, 1/2/4/8 GPUs",
             "value": round(value, 3),
@@ -334,16 +466,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": args.mode,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic: uniform [-2, 5], counter-based generator on the device, seed 12345",
             "config": {
-                "workload": f"{'S' if args.dtype == 'f32' else 'D'}GEMM {size}x{size}x{size} {args.trans.upper()} "
-                            f"per GPU C-block, alpha=1 beta=0, through sbamd_{'s' if args.dtype == 'f32' else 'd'}gemm",
+                "workload": workload,
                 "job": f"{gm}x{gn}x{gk}",
-                "grid": f"{pr}x{pc} C blocks",
-                "gather": bool(gathered is not None),
+                "grid": f"1x{world} column bands" if strong else f"{pr}x{pc} C blocks",
+                "gather": bool(gather),
                 "pct_of_mfma_peak_per_gpu": round(100.0 * value / world / peak, 2),
             },
             "roofline": {
@@ -352,11 +483,15 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": load_traffic(args.dtype, args.trans, size),
+                "traffic": load_traffic(args.dtype, args.trans, size) if world == 1 else None,
                 "kernel": f"gemm_mfma_kernel<{'float' if args.dtype == 'f32' else 'double'}> (tile family "
-                          f"{handle.last_kernel()}), {kernel_ms:.4f} ms per launch",
+                          f"{handle.last_kernel()}), {kernel_ms:.4f} ms per step of this rank's multiplications",
             },
         }
+        if args.rehearse:
+            out["config"]["rehearsal"] = "all ranks on GPU 0, collectives staged through the host: NOT a multi-GPU measurement"
+        if extras:
+            out["extras"] = extras
 
         if not args.no_extras and world == 1:
             out["extras"] = side_measurements(torch, sb, handle, size)

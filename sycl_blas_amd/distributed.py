@@ -9,6 +9,11 @@ exchange.  Collectives (RCCL through torch.distributed) appear only where data
 really moves:
 
   * all_gather_c      -- assemble the full C on every rank (optional);
+  * gathered_gemm     -- the strong-scaling schedule for a C that every rank needs whole:
+                         columns are dealt to the ranks band by band, each rank
+                         multiplies straight into its slot of the full column-major
+                         C, and band b's all-gather (in place, no re-layout) runs
+                         while band b + 1 is being multiplied;
   * splitk_gemm       -- K is cut across ranks instead, every rank produces a
                          full-size partial C, and a reduce-scatter sums them and
                          leaves each rank one column slab of the result.
@@ -142,3 +147,109 @@ def splitk_gemm(dist, torch, local_gemm, make_buffer, rank, world, transa, trans
     slab = torch.empty(m * (n // world), dtype=part_t.dtype, device=part_t.device)
     dist.reduce_scatter_tensor(slab, part_t, op=dist.ReduceOp.SUM, group=group)
     return slab, split_range(n, world, rank)
+
+
+def band_columns(rank, world, n, bands):
+    """Column ranges [(begin, end), ...] a rank computes in gathered_gemm, one per band.
+
+    Band b covers the global columns [b*W, (b+1)*W), W = n / bands, and is dealt to the
+    ranks in order: rank r takes [b*W + r*w, b*W + (r+1)*w), w = W / world.  In a
+    column-major C a band is then one contiguous run of m*W elements in which rank r's
+    part sits at r*(m*w): exactly the layout an in-place all-gather produces.
+    Needs n % (bands * world) == 0.
+    """
+    if n % (bands * world):
+        raise ValueError("band_columns needs n divisible by bands * ranks")
+    width = n // bands
+    w = width // world
+    return [(b * width + rank * w, b * width + (rank + 1) * w) for b in range(bands)]
+
+
+def pick_bands(world, m, n, k, max_bands=4, min_cols=512):
+    """How many column bands gathered_gemm cuts the product into: as many as divide n evenly
+    while every band GEMM (m x n/(bands*world) x k) keeps at least `min_cols` columns, so that it
+    still fills the chip with 64x64 / 128x128 tiles.  More bands hide more of the gather behind
+    the multiplication; fewer keep the multiplications efficient."""
+    bands = 1
+    for cand in range(2, max_bands + 1):
+        if n % (cand * world) == 0 and n // (cand * world) >= min_cols:
+            bands = cand
+    return bands
+
+
+class _NoStreams:
+    """Stream plumbing for ranks without a GPU (gloo tests): everything is already ordered."""
+
+    def gemm_done(self):
+        return None
+
+    def comm_section(self, after):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def finish(self, works):
+        for w in works:
+            if w is not None:
+                w.wait()
+
+
+class TorchStreams:
+    """Two HIP streams per rank: the GEMMs run on `compute` (the stream the library's handle was
+    created on), the collectives are launched from `comm`, which waits for each band's event."""
+
+    def __init__(self, torch, compute, comm=None):
+        self.torch = torch
+        self.compute = compute
+        self.comm = comm if comm is not None else torch.cuda.Stream()
+
+    def gemm_done(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.compute)
+        return ev
+
+    def comm_section(self, after):
+        self.comm.wait_event(after)
+        return self.torch.cuda.stream(self.comm)
+
+    def finish(self, works):
+        with self.torch.cuda.stream(self.comm):
+            for w in works:
+                if w is not None:
+                    w.wait()  # the comm stream waits for the collective
+        # the next multiplication into these slots must not start before the gathers have read them
+        self.compute.wait_stream(self.comm)
+
+
+def gathered_gemm(dist, local_gemm, rank, world, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, c_tensor,
+                  bands=1, streams=None, group=None, in_place=True):
+    """C = alpha * op(A) * op(B) + beta * C with the full column-major C (ldc = m) assembled on
+    every rank, multiplication and gather overlapped.
+
+    a, b address the FULL operands (replicated; a rank reads all of A and its own columns of
+    op(B)); c is the view of the rank's full C that local_gemm writes through, c_tensor the same
+    memory as a flat torch tensor of m*n elements for the collectives.  For band 0, 1, ...: the
+    rank multiplies its columns of the band straight into their final place, records an event,
+    and the band's all-gather is launched from the communication stream behind that event while
+    the next band is multiplied.  No re-layout: a band is contiguous and the ranks' parts lie in
+    rank order (band_columns).  With beta != 0 every rank must hold the same C on entry (its own
+    columns are read, the others are overwritten by the gather).
+    in_place=False sends a copy of the rank's part instead of the slice of the output itself
+    (for back ends that do not accept an input that aliases the output).
+    Returns the list of (begin, end) column ranges this rank multiplied.
+    """
+    streams = streams or _NoStreams()
+    cols = band_columns(rank, world, n, bands)
+    width = n // bands
+    works = []
+    for bi, (c0, c1) in enumerate(cols):
+        b_off = c0 * ldb if transb.lower() == "n" else c0
+        local_gemm(transa, transb, m, c1 - c0, k, alpha, a, lda, b + b_off, ldb, beta, c + c0 * m, m)
+        done = streams.gemm_done()
+        if world == 1:
+            continue
+        out = c_tensor[bi * width * m:(bi + 1) * width * m]
+        mine = c_tensor[c0 * m:c1 * m]
+        with streams.comm_section(done):
+            works.append(dist.all_gather_into_tensor(out, mine if in_place else mine.clone(), group=group, async_op=True))
+    streams.finish(works)
+    return cols

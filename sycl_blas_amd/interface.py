@@ -120,7 +120,8 @@ class DeviceBuffer:
 
     def __add__(self, n):
         n = int(n)
-        return DeviceBuffer(self.ptr + n * self.itemsize, self.dtype, self.count - n, self._owner or self)
+        return DeviceBuffer(self.ptr + n * self.itemsize, self.dtype, self.count - n,
+                            self._owner if self._owner is not None else self)
 
     @classmethod
     def from_pointer(cls, ptr, dtype, count, owner=None):
@@ -238,7 +239,7 @@ class helper:
 
     @staticmethod
     def deallocate(buf):
-        owner = buf._owner or buf
+        owner = buf._owner if buf._owner is not None else buf
         if isinstance(owner, _Allocation):
             owner.free()
 

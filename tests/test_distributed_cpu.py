@@ -69,7 +69,7 @@ def worker(rank, world, port, case, ret):
 
         # panels-only form: the rank holds just its row-panel / column-panel / block
         a_off, b_off = D.panel_offsets(rank, pr, pc, ta, tb, m, n, lda, ldb)
-        blk = np.ascontiguousarray(c0.reshape(n, m)[q0:q1, r0:r1]).ravel()
+        blk = c0.reshape(n, m)[q0:q1, r0:r1].copy().ravel()  # a copy: the block product must not write into c0
         D.block_gemm(oracle_gemm, rank, pr, pc, ta, tb, m, n, k, 1.5, HostView(a, a_off), lda, HostView(b, b_off), ldb,
                      0.5, HostView(blk), max(r1 - r0, 1), full_operands=False)
         ok_panels = np.array_equal(blk, mine)
@@ -85,7 +85,19 @@ def worker(rank, world, port, case, ret):
             ref = c0.copy() * 0
             oracle_gemm(ta, tb, m, n, k, 1.5, HostView(a), lda, HostView(b), ldb, 0.0, HostView(ref), m)
             ok_splitk = np.allclose(slab.numpy(), ref.reshape(n, m)[s0:s1].ravel(), rtol=2e-5, atol=1e-3)
-        ret[rank] = (ok_blocks, ok_panels, ok_splitk)
+        # the overlapped strong-scaling schedule: columns dealt band by band, multiplied in place into the
+        # full C, gathered band by band with no re-layout; must reproduce what all_gather_c assembles
+        ok_banded = True
+        for bands in (1, 2, 4):
+            if n % (bands * world):
+                continue
+            for in_place in (False, True):
+                c_t = torch.from_numpy(c0.copy())
+                cols = D.gathered_gemm(dist, oracle_gemm, rank, world, ta, tb, m, n, k, 1.5, HostView(a), lda, HostView(b),
+                                       ldb, 0.5, HostView(c_t.numpy()), c_t, bands=bands, in_place=in_place)
+                ok_banded &= np.array_equal(c_t.numpy(), gathered) and len(cols) == bands
+                ok_banded &= sum(c1 - c0_ for c0_, c1 in cols) * world == n
+        ret[rank] = (ok_blocks, ok_panels, ok_splitk, ok_banded)
     finally:
         dist.destroy_process_group()
 
@@ -104,7 +116,7 @@ def test_block_partition_and_collectives(world, case):
         assert p.exitcode == 0
     assert len(ret) == world
     for r in range(world):
-        assert ret[r] == (True, True, True), (r, ret[r])
+        assert ret[r] == (True, True, True, True), (r, ret[r])
 
 
 def test_partition_covers_c_exactly_once():
@@ -121,3 +133,21 @@ def test_partition_covers_c_exactly_once():
             assert total == m * n
             assert (seen == 1).all()
     assert D.grid_for(8) == (2, 4) and D.grid_for(4) == (2, 2) and D.grid_for(2) == (1, 2)
+
+
+def test_band_columns_tile_every_band_in_rank_order():
+    for world, n, bands in ((8, 8192, 2), (4, 8192, 4), (2, 64, 4), (1, 12, 3)):
+        seen = np.zeros(n, np.int32)
+        width = n // bands
+        for r in range(world):
+            cols = D.band_columns(r, world, n, bands)
+            assert len(cols) == bands
+            for bi, (c0, c1) in enumerate(cols):
+                assert c0 == bi * width + r * (width // world) and c1 - c0 == width // world
+                seen[c0:c1] += 1
+        assert (seen == 1).all()
+    with pytest.raises(ValueError):
+        D.band_columns(0, 3, 8192, 2)
+    # every band GEMM keeps at least 512 columns
+    assert D.pick_bands(8, 8192, 8192, 8192) == 2 and D.pick_bands(4, 8192, 8192, 8192) == 4
+    assert D.pick_bands(2, 8192, 8192, 8192) == 4 and D.pick_bands(8, 8192, 1024, 8192) == 1
