@@ -234,7 +234,24 @@ def cpu_baseline(dtype, ta, tb, size, seed):
         openblas = round(2.0 * sz ** 3 / (time.perf_counter() - t1) / 1e12, 4)
     except Exception:
         pass
+    # BASELINE config #1 (SGEMM 1024^3 NN on the reference's CPU back end): the restatement of the kernel
+    # that back end picks for it (no_local, partial, Tile<4,4,4,4>; src/interface/blas3/backend/default.hpp:98-112),
+    # whole product, best of three
+    n1 = 1024
+    a1 = uniform_reference(n1 * n1, 778).astype(np.float32)
+    b1 = uniform_reference(n1 * n1, 779).astype(np.float32)
+    c1 = np.zeros(n1 * n1, dtype=np.float32)
+    best = 1e30
+    for _ in range(4):
+        t1 = time.perf_counter()
+        oracle.gemm_default_tile("n", "n", n1, n1, n1, 1.0, a1, n1, b1, n1, 0.0, c1, n1)
+        best = min(best, time.perf_counter() - t1)
+    config1 = {"value": round(2.0 * n1 ** 3 / best / 1e12, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+               "ms": round(best * 1e3, 3),
+               "sample": "whole SGEMM 1024^3 NN (config #1), restatement of the reference's DEFAULT-back-end kernel "
+                         "(no_local partial, Tile<4,4,4,4>, 16x16 C tile per work-group), OpenMP over work-groups"}
     return {
+        "config1_sgemm_1024": config1,
         "openblas_tflops_4096": openblas,
         "value": round(2.0 * m * cols * k / dt / 1e12, 5),
         "unit": "TFLOP/s",
@@ -242,7 +259,7 @@ def cpu_baseline(dtype, ta, tb, size, seed):
         "kind": "port",
         "sample": f"first {cols} of {size} columns of C of the same {dtype} {size}^3 {ta}{tb} product "
                   f"({2.0 * m * cols * k / 1e9:.0f} GFLOP, {dt:.2f} s), OpenMP over columns",
-    }, c, cols
+    }, c, cols, c1
 
 
 def load_traffic(dtype, trans, size):
@@ -498,8 +515,15 @@ def main():
 
         if not args.no_cpu and world == 1:
             try:
-                base, c_cpu, cols = cpu_baseline(args.dtype, ta, tb, size, 12345)
+                base, c_cpu, cols, c_1024 = cpu_baseline(args.dtype, ta, tb, size, 12345)
                 out["cpu_baseline"] = base
+                # config #1 on the GPU (same seeds as the CPU leg) must give the CPU kernel's bits
+                o1 = Operands(torch, sb, handle, "f32", "n", "n", 1024, 1024, 1024, 778)
+                o1.run(sb, handle)
+                got1 = np.empty(1024 * 1024, dtype=np.float32)
+                handle.wait(sb.helper.copy_to_host(handle, o1.c, got1, got1.size))
+                base["config1_sgemm_1024"]["gpu_bitwise_equal"] = bool(np.array_equal(got1.view(np.uint8), c_1024.view(np.uint8)))
+                base["config1_sgemm_1024"]["gpu_split_k"] = list(handle.last_splitk())
                 # the GPU result of the same product must equal the CPU restatement bit for bit
                 got = np.empty(size * cols, dtype=NP_DTYPE[args.dtype])
                 handle.wait(sb.helper.copy_to_host(handle, ops.c, got, got.size))

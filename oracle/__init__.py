@@ -45,6 +45,9 @@ def load():
         f.restype = C.c_int
         f.argtypes = [C.c_int, C.c_char, C.c_char, i64, i64, i64, sc, vp, i64, i64, vp, i64, i64, sc, vp,
                       i64, i64, i64, C.c_int, i64, i64]
+        f = getattr(lib, "oracle_gemm_default_tile_" + suf)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, C.c_int, i64, i64, i64, sc, vp, i64, vp, i64, sc, vp, i64]
     lib.oracle_gemm_truth.restype = C.c_int
     lib.oracle_gemm_truth.argtypes = [C.c_int, C.c_int, i64, i64, i64, C.c_double, vp, i64, vp, i64,
                                       C.c_double, vp, i64, vp, vp, i64]
@@ -87,6 +90,17 @@ def gemm_backend(transa, transb, m, n, k, alpha, a, lda, stride_a, b, ldb, strid
     return fn(form, _ch(transa), _ch(transb), m, n, k, sc(alpha), a.ctypes.data + a_off * isz, lda,
               stride_a, b.ctypes.data + b_off * isz, ldb, stride_b, sc(beta), c.ctypes.data + c_off * isz,
               ldc, stride_c, batch, int(batch_type), depth, k_chunk if k_chunk > 0 else max(k, 1))
+
+
+def gemm_default_tile(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
+    """One GEMM through the restatement of the kernel the reference's CPU back end runs for M*N >= 524288
+    (no_local, partial, Tile<4,4,4,4>: src/interface/blas3/backend/default.hpp:98-112); c is updated in place."""
+    lib = load()
+    suf, sc = _suffix(c)
+    assert a.dtype == c.dtype and b.dtype == c.dtype
+    return getattr(lib, "oracle_gemm_default_tile_" + suf)(int(transa.lower() != "n"), int(transb.lower() != "n"), m, n, k,
+                                                           sc(alpha), a.ctypes.data, lda, b.ctypes.data, ldb, sc(beta),
+                                                           c.ctypes.data, ldc)
 
 
 def default_strides(transa, transb, m, n, k, lda, ldb, ldc):

@@ -261,6 +261,69 @@ enum {
 DEFINE_ORACLE(float, f32, fmaf)
 DEFINE_ORACLE(double, f64, fma)
 
+/* The kernel the reference's DEFAULT (CPU) back end picks when M*N >= 524288, i.e. for
+ * BASELINE config #1 (SGEMM 1024^3): src/interface/blas3/backend/default.hpp:98-112 --
+ * Gemm<no_local, standard, partial> with Tile<4, 4, 4, 4>, vector size 1, no double buffer.
+ * Restated loop for loop from src/operations/blas3/gemm_no_local_partial_vec.hpp:
+ *   - work-groups of wg_rows*wg_cols = 16 items own block_rows x block_cols = 16 x 16 tiles of C,
+ *     numbered row-tile first (:215-228);
+ *   - item (item_id % wg_rows, item_id / wg_rows) holds an item_rows x item_cols = 4 x 4 register
+ *     block whose rows / columns are wg_rows / wg_cols apart (:243-262, :321-333);
+ *   - reg_res starts at (beta/alpha)*C, beta/alpha formed on the host (:129, :313-335), or 0 when
+ *     beta == 0 (:340-347);
+ *   - one k per trip: item_rows elements of A and item_cols of B straight from global memory
+ *     (zero past the edge, :454-486), 16 mul_add (:374-401, :495-505);
+ *   - C <- alpha * reg_res (:544-579).
+ * The work-groups run as an OpenMP loop and the 16 items of a group one after the other, which
+ * is how an OpenMP SYCL back end executes a barrier-free kernel.  This is the CPU baseline for
+ * config #1: same arithmetic per element as ORC_FORM_LOCAL (asserted in the tests), the
+ * reference's memory access pattern and blocking. */
+#define DEFINE_DEFAULT_TILE(T, SUF, FMA)                                                        \
+  int oracle_gemm_default_tile_##SUF(int ta, int tb, int64_t m, int64_t n, int64_t k, T alpha,  \
+                                     const T* a, int64_t lda, const T* b, int64_t ldb, T beta,  \
+                                     T* c, int64_t ldc) {                                       \
+    enum { IR = 4, IC = 4, WR = 4, WC = 4, BR = IR * WR, BC = IC * WC };                        \
+    if (m <= 0 || n <= 0) return ORC_OK;                                                        \
+    const int beta_zero = (beta == (T)0);                                                       \
+    const T ratio = beta / alpha; /* :129 */                                                    \
+    const int64_t blocks_per_row = (m - 1) / BR + 1;                                            \
+    const int64_t cluster = blocks_per_row * ((n - 1) / BC + 1); /* :153-156 */                 \
+    const int64_t a_row = ta ? lda : 1, a_k = ta ? 1 : lda;      /* :260, :399 */               \
+    const int64_t b_col = tb ? 1 : ldb, b_k = tb ? ldb : 1;      /* :261, :400 */               \
+    _Pragma("omp parallel for schedule(static)") for (int64_t wg = 0; wg < cluster; ++wg) {     \
+      const int64_t wg_row = (wg % blocks_per_row) * BR, wg_col = (wg / blocks_per_row) * BC;   \
+      for (int item = 0; item < WR * WC; ++item) {                                              \
+        const int64_t row0 = wg_row + item % WR, col0 = wg_col + item / WR;                     \
+        if (row0 >= m || col0 >= n) continue; /* out_of_range, :250 */                          \
+        T reg_res[IR * IC], reg_a[IR], reg_b[IC];                                               \
+        for (int i = 0; i < IC; ++i)                                                            \
+          for (int j = 0; j < IR; ++j) {                                                        \
+            const int64_t r = row0 + j * WR, cc = col0 + i * WC;                                \
+            reg_res[i * IR + j] = (!beta_zero && r < m && cc < n) ? ratio * c[r + cc * ldc] : (T)0; \
+          }                                                                                     \
+        const T* pa = a + row0 * a_row;                                                         \
+        const T* pb = b + col0 * b_col;                                                         \
+        for (int64_t l = 0; l < k; ++l) {                                                       \
+          for (int j = 0; j < IR; ++j) reg_a[j] = (row0 + j * WR < m) ? pa[j * WR * a_row] : (T)0; \
+          for (int i = 0; i < IC; ++i) reg_b[i] = (col0 + i * WC < n) ? pb[i * WC * b_col] : (T)0; \
+          for (int i = 0; i < IC; ++i)                                                          \
+            for (int j = 0; j < IR; ++j) reg_res[i * IR + j] = FMA(reg_a[j], reg_b[i], reg_res[i * IR + j]); \
+          pa += a_k;                                                                            \
+          pb += b_k;                                                                            \
+        }                                                                                       \
+        for (int i = 0; i < IC; ++i)                                                            \
+          for (int j = 0; j < IR; ++j) {                                                        \
+            const int64_t r = row0 + j * WR, cc = col0 + i * WC;                                \
+            if (r < m && cc < n) c[r + cc * ldc] = alpha * reg_res[i * IR + j];                 \
+          }                                                                                     \
+      }                                                                                         \
+    }                                                                                           \
+    return ORC_OK;                                                                              \
+  }
+
+DEFINE_DEFAULT_TILE(float, f32, fmaf)
+DEFINE_DEFAULT_TILE(double, f64, fma)
+
 /* Status codes of the GEMM callers (numerically equal to include/sbamd_gemm.h). */
 enum {
   ORC_INVALID_UPLO = 11,

@@ -11,6 +11,7 @@
 // call for call, with the block inverter as a small HIP kernel.
 #include <algorithm>
 #include <cctype>
+#include <type_traits>
 
 #include "gemm_mfma.hpp"
 #include "sbamd_internal.hpp"
@@ -30,55 +31,73 @@ __global__ void __launch_bounds__(256)
 }
 
 // Inverse of every 16x16 diagonal block of the triangular matrix A (n x n), written as
-// consecutive column-major 16x16 blocks.  One 16-lane group per block, lane = row;
-// the arithmetic (reciprocal of the diagonal, fma chains in k order, one final
-// multiply) is that of src/operations/blas3/trsm.hpp:93-153 step for step.
-// Elements outside the stored triangle or outside the matrix count as zero and are
-// never read.
+// consecutive column-major 16x16 blocks.  A wavefront handles four blocks, 16 lanes each; a lane
+// owns one ROW of its block in registers.  Column j of the inverse needs, in every row above (upper)
+// or below (lower) the diagonal, the product of that row's finished part with the still original
+// column j of the block -- whose element (k, j) sits in lane k's register j and reaches the other
+// lanes of the group by a lane shuffle.  No LDS, no barrier (the reference's form, 30 barriers per
+// block over a shared 16x16 array: src/operations/blas3/trsm.hpp:93-153).  The arithmetic is that
+// form's, value for value: reciprocal of the diagonal, one fma chain per element over k in the same
+// order with the same operands (zeros of the other triangle included), one final multiply by the
+// negated reciprocal -- so the inverted blocks, and with them every _trsm result, keep their bits.
+// Elements outside the stored triangle or outside the matrix count as zero and are never read.
 template <typename T, bool UNIT, bool UPPER>
 __global__ void __launch_bounds__(64)
     trsm_invert_blocks_kernel(const T* __restrict__ a, int64_t lda, int64_t n, int64_t nblocks, T* __restrict__ inv) {
   constexpr int B = 16;
-  __shared__ T lds[4][B * B];
-  const int sub = threadIdx.x >> 4;
-  const int i = threadIdx.x & 15;
-  const int64_t blk = int64_t(blockIdx.x) * 4 + sub;
+  const int i = threadIdx.x & 15;  // the row this lane owns
+  const int64_t blk = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 4);
   const bool live = blk < nblocks;
-  T* local = lds[sub];  // local[j + i*B] = element (row i, column j)
   const int64_t origin = blk * B;
-  for (int j = 0; j < B; ++j) {
+  T row[B];  // row[c] = element (i, c)
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
     bool in_range = false;
-    if (live) in_range = UPPER ? (i <= j) && (origin + j < n) : (i >= j) && (origin + i < n);
+    if (live) in_range = UPPER ? (i <= c) && (origin + c < n) : (i >= c) && (origin + i < n);
     T v = T(0);
-    if (in_range) v = (UNIT && i == j) ? T(1) : a[(origin + j) * lda + origin + i];
-    local[j + i * B] = v;
+    if (in_range) v = (UNIT && i == c) ? T(1) : a[(origin + c) * lda + origin + i];
+    row[c] = v;
   }
-  __syncthreads();
   if (!UNIT) {
-    local[i + i * B] = T(1) / local[i + i * B];
-    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      if (c == i) row[c] = T(1) / row[c];
   }
+  // one column of the inverse per step; every lane runs the same shuffles, the rows the column
+  // does not reach keep their value
+  auto column = [&](auto j_tag) {
+    constexpr int J = decltype(j_tag)::value;
+    T sum = T(0);
+    if (UPPER) {
+#pragma unroll
+      for (int k = 0; k < J; ++k) sum = fma_rn(row[k], __shfl(row[J], k, B), sum);
+    } else {
+#pragma unroll
+      for (int k = J + 1; k < B; ++k) sum = fma_rn(row[k], __shfl(row[J], k, B), sum);
+    }
+    const T diag = __shfl(row[J], J, B);
+    const T scaled = sum * (UNIT ? T(-1) : -diag);
+    const bool mine = UPPER ? i < J : i > J;
+    row[J] = mine ? scaled : row[J];
+  };
+  auto columns = [&](auto... js) { (column(js), ...); };
+  using std::integral_constant;
   if (UPPER) {
-    for (int j = 1; j < B; ++j) {
-      T sum = T(0);
-      if (i < j)
-        for (int k = 0; k < j; ++k) sum = fma_rn(local[k + i * B], local[j + k * B], sum);
-      __syncthreads();
-      if (i < j) local[j + i * B] = sum * (UNIT ? T(-1) : -local[j + j * B]);
-      __syncthreads();
-    }
+    columns(integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
+            integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{}, integral_constant<int, 8>{},
+            integral_constant<int, 9>{}, integral_constant<int, 10>{}, integral_constant<int, 11>{},
+            integral_constant<int, 12>{}, integral_constant<int, 13>{}, integral_constant<int, 14>{},
+            integral_constant<int, 15>{});
   } else {
-    for (int j = B - 2; j >= 0; --j) {
-      T sum = T(0);
-      if (i > j)
-        for (int k = j + 1; k < B; ++k) sum = fma_rn(local[k + i * B], local[j + k * B], sum);
-      __syncthreads();
-      if (i > j) local[j + i * B] = sum * (UNIT ? T(-1) : -local[j + j * B]);
-      __syncthreads();
-    }
+    columns(integral_constant<int, 14>{}, integral_constant<int, 13>{}, integral_constant<int, 12>{},
+            integral_constant<int, 11>{}, integral_constant<int, 10>{}, integral_constant<int, 9>{}, integral_constant<int, 8>{},
+            integral_constant<int, 7>{}, integral_constant<int, 6>{}, integral_constant<int, 5>{}, integral_constant<int, 4>{},
+            integral_constant<int, 3>{}, integral_constant<int, 2>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{});
   }
-  if (live)
-    for (int j = 0; j < B; ++j) inv[blk * B * B + j * B + i] = local[j + i * B];
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < B; ++c) inv[blk * B * B + c * B + i] = row[c];
+  }
 }
 
 // Solves a diagonal super-block of up to 128 rows (columns on the right side) of the

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm_mfma.hpp"
@@ -23,6 +24,17 @@ inline bool vec_ok(const T* p, int64_t ld, int64_t stride, int64_t batch) {
   constexpr int V = 16 / sizeof(T);
   return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % V == 0) &&
          (batch <= 1 || stride % V == 0);
+}
+
+// SBAMD_GROUP_M=<n> overrides the band height of the workgroup -> tile map for every launch (a tuning
+// switch for counter sweeps; the result does not depend on it).
+inline int group_m_override() {
+  static const int value = [] {
+    const char* e = std::getenv("SBAMD_GROUP_M");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 && v <= 64 ? v : 0;
+  }();
+  return value;
 }
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB>
@@ -296,6 +308,9 @@ hipError_t launch_huge(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
                 : launch_one<T, 256, 256, Tiles<T>::HUGE_BK, 2, 4, Tiles<T>::HUGE_OCC, false, false>(g, nz, stream);
     }
   }
+  // 256 x 128 tiles (double): bands of 4 tile rows make the 32 tiles resident on an XCD a 4 x 8 patch, which
+  // shares more operand rows in that XCD's L2 than 8 x 4 does (4*256 + 8*128 against 8*256 + 4*128 per K step)
+  if (g.group_m == 0 && Tiles<T>::HUGE_BN == 128) g.group_m = 4;
   return launch_tile<T, 256, Tiles<T>::HUGE_BN, Tiles<T>::HUGE_BK, 4, 2, Tiles<T>::HUGE_OCC>(g, ta, tb, stream);
 }
 
@@ -399,6 +414,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   g.alpha = p.alpha;
   g.beta = p.beta;
   g.beta_zero = p.beta_zero ? 1 : 0;
+  g.group_m = group_m_override();  // 0 = each tile family's default (launch_huge sets double's)
 
   if (p.interleaved) {
     // First branch of the reference's dispatch (amd_gpu.hpp:58-74).  Small items run

@@ -55,6 +55,7 @@ struct GemmArgs {
   int32_t vec_a, vec_b;                  // 16-byte loads are legal for A / B
   T alpha, beta;
   int32_t beta_zero;                     // never read C
+  int32_t group_m;                       // rows of tiles per band of the workgroup -> tile map (0: the default)
 };
 
 // ---------------------------------------------------------------- MFMA shapes
@@ -266,12 +267,16 @@ __device__ inline int xcd_remap(int bid, int nwg) {
 
 // Rows of tiles are walked in bands of GROUP_M so that a run of consecutive
 // logical ids touches few distinct A and B panels.
+// The 32 workgroups resident on one XCD (one per compute unit) then form a GROUP_M x 32/GROUP_M patch
+// of C and share (GROUP_M * BM + 32/GROUP_M * BN) of the 32 * (BM + BN) operand rows they request per
+// K step from that XCD's L2: 8 x 4 for square tiles, 4 x 8 for the 256 x 128 tile of double.
 constexpr int GROUP_M = 8;
-__device__ inline void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int band = GROUP_M * tiles_n;
+__device__ inline void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn, int group_m = GROUP_M) {
+  if (group_m <= 0) group_m = GROUP_M;
+  const int band = group_m * tiles_n;
   const int g = t / band;
-  const int first_m = g * GROUP_M;
-  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+  const int first_m = g * group_m;
+  const int gsz = (tiles_m - first_m) < group_m ? (tiles_m - first_m) : group_m;
   const int in = t - g * band;
   tm = first_m + in % gsz;
   tn = in / gsz;
@@ -651,7 +656,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int z = logical / ntiles;
   int tm, tn;
-  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
+  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn, g.group_m);
   const int64_t m0 = int64_t(tm) * BM;
   const int64_t n0 = int64_t(tn) * BN;
 
@@ -749,7 +754,7 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int z = logical / ntiles;
   int tm, tn;
-  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
+  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn, g.group_m);
   const int64_t m0 = int64_t(tm) * BM;
   const int64_t n0 = int64_t(tn) * BN;
   const T* a = g.a + int64_t(z) * g.stride_a;
@@ -909,7 +914,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int z = logical / ntiles;
   int tm, tn;
-  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
+  tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn, g.group_m);
   const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
 
   const float* a = g.a;
@@ -1215,7 +1220,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   const int wn = wave / WM;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
-  tile_coords(logical, g.tiles_m, g.tiles_n, tm, tn);
+  tile_coords(logical, g.tiles_m, g.tiles_n, tm, tn, g.group_m);
   const int64_t m0 = int64_t(tm) * BM;
   const int64_t n0 = int64_t(tn) * BN;
   const int frag_mn = M::lane_mn(lane);

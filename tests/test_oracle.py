@@ -181,3 +181,32 @@ def test_golden_fixtures():
                                  ldc, sc, batch=batch, form=form, depth=depth, k_chunk=k_chunk)
         assert st == 0
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), name
+
+
+def test_default_backend_tile_kernel_equals_the_local_form():
+    """The restatement of the kernel the reference's CPU back end runs for config #1 (no_local partial,
+    Tile<4,4,4,4>: src/interface/blas3/backend/default.hpp:98-112,
+    src/operations/blas3/gemm_no_local_partial_vec.hpp:189-416) computes, element for element, the
+    alpha*((beta/alpha)*C + sum) form of every tiled kernel: whole buffers, ragged edges in both
+    dimensions, padded leading dimensions, every transpose, beta zero and non-zero."""
+    rng = np.random.default_rng(2024)
+    for dtype in (np.float32, np.float64):
+        for (m, n, k), ta, tb in itertools.product([(37, 29, 19), (64, 48, 33), (17, 100, 5), (130, 131, 40), (1, 1, 1)],
+                                                   "nt", "nt"):
+            lda = (k if ta != "n" else m) + 3
+            ldb = (n if tb != "n" else k) + 2
+            ldc = m + 1
+            a = rng.uniform(-2, 5, lda * (m if ta != "n" else k)).astype(dtype)
+            b = rng.uniform(-2, 5, ldb * (k if tb != "n" else n)).astype(dtype)
+            c0 = rng.uniform(-2, 5, ldc * n).astype(dtype)
+            for alpha, beta in ((1.5, 0.5), (2.0, 0.0)):
+                got, want = c0.copy(), c0.copy()
+                assert oracle.gemm_default_tile(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, got, ldc) == 0
+                assert oracle.gemm_backend(ta, tb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, want, ldc, 0,
+                                           form=oracle.FORM_LOCAL) == 0
+                assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, m, n, k, ta, tb, alpha, beta)
+    # beta == 0 never reads C (NaN in C must not survive)
+    c = np.full(16 * 16, np.nan, np.float32)
+    ones = np.ones(16 * 16, np.float32)
+    oracle.gemm_default_tile("n", "n", 16, 16, 16, 1.0, ones, 16, ones, 16, 0.0, c, 16)
+    assert (c == 16).all()
