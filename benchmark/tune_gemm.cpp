@@ -24,7 +24,7 @@
 
 namespace {
 
-FILE* g_csv = nullptr;  // --csv=FILE: one line per candidate (dtype,ta,tb,m,k,n,bs,kernel,tile,depth,ms)
+FILE* g_csv = nullptr;  // --csv=FILE: one line per candidate (dtype,ta,tb,m,k,n,bs,kernel,tile,depth,ms,fused)
 
 void check(int st, sbamd_handle_t h, const char* what) {
   if (st == SBAMD_OK) return;
@@ -166,9 +166,9 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     std::printf("  %-32s %10.4f ms %12.1f GFLOP/s  %s%s\n", o.cand.name.c_str(), o.ms, o.gflops, o.note.c_str(),
                 o.same_bits ? "" : "  RESULT DIFFERS");
     if (g_csv)
-      std::fprintf(g_csv, "%s,%c,%c,%lld,%lld,%lld,%lld,%d,%d,%d,%.6f\n", sizeof(T) == 4 ? "float" : "double", ta, tb,
+      std::fprintf(g_csv, "%s,%c,%c,%lld,%lld,%lld,%lld,%d,%d,%d,%.6f,%d\n", sizeof(T) == 4 ? "float" : "double", ta, tb,
                    (long long)m, (long long)k, (long long)n, (long long)bs, o.cand.kernel, (o.cand.param >> 16) & 0xff,
-                   o.cand.param & 0xffff, o.ms);
+                   o.cand.param & 0xffff, o.ms, (o.cand.param >> 24) & 1);
   }
   for (const Outcome& o : outcomes)
     if (o.ok && !o.same_bits) throw std::runtime_error("kernel families disagree on this shape");

@@ -36,6 +36,11 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef SBAMD_ABLATE
 #define SBAMD_ABLATE 0
 #endif
+// Wavefront tiles of at most this many matrix tiles take the K loop with fragments two groups ahead and the
+// operand traffic spread over the step (run_pipelined_far).
+#ifndef SBAMD_FAR_MAX_TILES
+#define SBAMD_FAR_MAX_TILES 1
+#endif
 
 // Arguments shared by every kernel in this file.  Pointers are typed in the
 // kernels; sizes are 64-bit so 65536 x 65536 operands index correctly.
@@ -184,6 +189,16 @@ struct TileLoader {
     }
   }
 
+  // One vector of the tile: load_fast / store taken apart so that a K loop can spread them between its
+  // matrix instructions (store vector i, then request its successor into the registers just freed).
+  template <int DIR = 1>
+  __device__ inline void load_one(int64_t ld, int i) {
+    const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(ptr[i]);
+#pragma unroll
+    for (int e = 0; e < V; ++e) reg[i][e] = vv[e];
+    ptr[i] += DIR * (KMAJOR ? int64_t(BK) : int64_t(BK) * ld);
+  }
+
   // Edge tile, K tail or unaligned operand: element loads.  Rows/columns past
   // the matrix edge re-read the last valid one (they only feed C elements that
   // are never stored); k past the end contributes exactly zero.
@@ -209,21 +224,26 @@ struct TileLoader {
 
   __device__ inline void store(SBAMD_LDS T* lds, int tid) const {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    for (int i = 0; i < NV; ++i) store_one(lds, tid, i);
+  }
+
+  __device__ inline void store_one(SBAMD_LDS T* lds, int tid, int i) const {
+    {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
       SBAMD_LDS T* p = lds + row * S + col;
       if (KMAJOR && V == 4) {
-        // (k0, k2, k1, k3): two 8-byte stores (the row stride is only 8-byte aligned)
-        typedef T pair_t __attribute__((ext_vector_type(2)));
-        pair_t lo, hi;
-        lo[0] = reg[i][0];
-        lo[1] = reg[i][2];
-        hi[0] = reg[i][1];
-        hi[1] = reg[i][3];
-        *reinterpret_cast<SBAMD_LDS pair_t*>(p) = lo;
-        *reinterpret_cast<SBAMD_LDS pair_t*>(p + 2) = hi;
+        // (k0, k2, k1, k3), written element by element.  (Built from 8-byte vector stores, the register
+        // pairs (k0, k2) / (k1, k3) have to be assembled first, and hipcc assembles them right behind the
+        // global loads at the bottom of the K loop -- waiting there for loads it has just issued, every
+        // step.)  volatile keeps the vectoriser from re-forming those pairs; the stores stay visible to
+        // the compiler's wait counting.
+        volatile SBAMD_LDS T* q = p;
+        q[0] = reg[i][0];
+        q[1] = reg[i][2];
+        q[2] = reg[i][1];
+        q[3] = reg[i][3];
       } else {
         typename M::vec_t vv;
 #pragma unroll
@@ -427,12 +447,113 @@ struct GemmBody {
     mma_group(fa[(K::NGRP - 1) & 1], fb[(K::NGRP - 1) & 1]);
   }
 
+  // ---- the pipelined path for one matrix tile per wavefront (64 x 64 workgroup tile, 32 x 32 tile) --------
+  //
+  // A fragment group is then only two matrix instructions (128 cycles) long and a wavefront has no second
+  // accumulator to turn to: a fragment that is read one group ahead is waited for about one matrix instruction
+  // after its read was issued, less than an LDS read takes.  Here the fragments run TWO groups ahead through
+  // four register slots (group g in slot g & 3; NGRP is a multiple of four, so a K step hands over in slots 0
+  // and 1 again), and the order is fixed with scheduling fences instead of a pattern: reads of group g + 2,
+  // then the matrix instructions of group g.  The barrier sits in front of the last two groups' matrix
+  // instructions; behind it the first two groups of the next tile are fetched.
+  using far_a_t = T[4][K::MI][M::GS];
+  using far_b_t = T[4][K::NI][M::GS];
+
+  // MOVE: this step also moves operand data -- vector by vector, one piece behind the fragment reads of each
+  // of the first groups: store vector i of tile kt + 1 to LDS (STORE), then request vector i of tile kt + 2
+  // into the registers just freed (LOAD).  Bunched at the top of the step instead, the four wavefronts issue
+  // ten LDS stores and four 1-KiB loads each at the same moment and wait on the queues in front of the LDS
+  // and the texture path before their first matrix instruction.
+  template <bool HAS_NEXT, bool STORE, bool LOAD>
+  __device__ inline void far_step(const GemmArgs<T>& g, const SBAMD_LDS T* as, const SBAMD_LDS T* bs, SBAMD_LDS T* nas,
+                                  SBAMD_LDS T* nbs, int a_mn, int b_mn, int lane, int tid, far_a_t& fa, far_b_t& fb) {
+    static_assert(K::NGRP % 4 == 0, "the fragment slots must come back to 0 / 1 at the end of a K step");
+    constexpr int PIECES = LoadA::NV + LoadB::NV;
+    constexpr int PER = (PIECES + K::NGRP - 3) / (K::NGRP - 2);  // pieces per group, all in front of the barrier
+#pragma unroll
+    for (int grp = 0; grp < K::NGRP; ++grp) {
+      if (grp + 2 == K::NGRP) __syncthreads();
+      if (grp + 2 < K::NGRP) fetch_group(as, bs, grp + 2, a_mn, b_mn, lane, fa[(grp + 2) & 3], fb[(grp + 2) & 3]);
+      else if (HAS_NEXT) fetch_group(nas, nbs, grp + 2 - K::NGRP, a_mn, b_mn, lane, fa[(grp + 2) & 3], fb[(grp + 2) & 3]);
+      if (STORE) {
+#pragma unroll
+        for (int q = grp * PER; q < (grp + 1) * PER && q < PIECES; ++q) {
+          if (q < LoadA::NV) {
+            la.store_one(nas, tid, q);
+            if (LOAD) la.load_one(g.lda, q);
+          } else {
+            lb.store_one(nbs, tid, q - LoadA::NV);
+            if (LOAD) lb.load_one(g.ldb, q - LoadA::NV);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group(fa[grp & 3], fb[grp & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  __device__ inline void run_pipelined_far(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
+                                           int64_t k_begin, int64_t k_end, SBAMD_LDS T* smem, int tid, int a_mn,
+                                           int b_mn) {
+    const int lane = tid & 63;
+    const int nfull = int((k_end - k_begin) / BK);  // >= 1 (checked by the caller)
+    SBAMD_LDS T* const buf0 = smem;
+    SBAMD_LDS T* const buf1 = smem + K::STAGE_ELEMS;
+    la.init_fast(a, g.lda, m0, g.m, k_begin, tid);
+    lb.init_fast(b, g.ldb, n0, g.n, k_begin, tid);
+    la.load_fast(g.lda);
+    lb.load_fast(g.ldb);
+    la.store(buf0, tid);
+    lb.store(buf0 + K::A_ELEMS, tid);
+    if (nfull > 1) {
+      la.load_fast(g.lda);
+      lb.load_fast(g.ldb);
+    }
+    __syncthreads();
+    far_a_t fa;
+    far_b_t fb;
+    fetch_group(buf0, buf0 + K::A_ELEMS, 0, a_mn, b_mn, lane, fa[0], fb[0]);
+    fetch_group(buf0, buf0 + K::A_ELEMS, 1, a_mn, b_mn, lane, fa[1], fb[1]);
+
+    int kt = 0;
+    for (; kt + 2 < nfull; ++kt) {
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
+      // tile kt + 1 (loaded one step ago) goes to LDS, tile kt + 2 is requested into the freed registers
+      far_step<true, true, true>(g, cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, tid, fa, fb);
+    }
+    if (kt + 1 < nfull) {  // last but one: nothing left to request
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
+      far_step<true, true, false>(g, cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, tid, fa, fb);
+      ++kt;
+    }
+    {
+      SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
+      far_step<false, false, false>(g, cur, cur + K::A_ELEMS, cur, cur + K::A_ELEMS, a_mn, b_mn, lane, tid, fa, fb);
+    }
+    const int64_t k_tail = k_begin + int64_t(nfull) * BK;
+    if (k_tail < k_end) {
+      la.load_edge(a, g.lda, m0, g.m, k_tail, k_end, tid);
+      lb.load_edge(b, g.ldb, n0, g.n, k_tail, k_end, tid);
+      la.store(buf0, tid);
+      lb.store(buf0 + K::A_ELEMS, tid);
+      __syncthreads();
+      compute<0>(buf0, buf0 + K::A_ELEMS, a_mn, b_mn, lane);
+    }
+  }
+
   __device__ inline void run_pipelined(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0,
                                        int64_t n0, int64_t k_begin, int64_t k_end, SBAMD_LDS T* smem,
                                        int tid, int a_mn, int b_mn) {
     const int lane = tid & 63;
     const int64_t klen = k_end - k_begin;
     const int nfull = int(klen / BK);  // >= 1 (checked by the caller)
+    if constexpr (K::MI * K::NI <= SBAMD_FAR_MAX_TILES && K::NGRP % 4 == 0 && !SBAMD_ABLATE) {
+      run_pipelined_far(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
+      return;
+    }
     constexpr int NW = LoadA::NWRITE + LoadB::NWRITE;
     constexpr int NL = LoadA::NV + LoadB::NV;
     SBAMD_LDS T* const buf0 = smem;
@@ -465,6 +586,11 @@ struct GemmBody {
         la.load_fast(g.lda);
         lb.load_fast(g.ldb);
       }
+      // One matrix tile per wavefront (the 64 x 64 workgroup tile, one wavefront per SIMD): nothing else
+      // hides a load that is waited for early, and left to itself the scheduler sinks these loads to the
+      // bottom of the step, a few hundred cycles in front of the LDS store that needs them.  Keep them
+      // here, a whole K step ahead of that store.
+      if constexpr (K::MI * K::NI == 1) __builtin_amdgcn_sched_barrier(0);
       pipelined_step<true, NW, NL>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
     }
     if (kt + 1 < nfull) {  // last but one: nothing left to load

@@ -2,6 +2,7 @@
 torch.matmul on the same GPU, same memory problem, over a list of shapes -- to find the shapes
 where a kernel or the planner leaves the most on the table.
 Usage: python tools/compare_vendor.py [f32|f64] [--csv out.csv]"""
+import ctypes as C
 import os
 import sys
 
@@ -9,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sycl_blas_amd as sb  # noqa: E402
-from sycl_blas_amd import DeviceBuffer  # noqa: E402
+from sycl_blas_amd import DeviceBuffer, _lib  # noqa: E402
 
 SHAPES = (
     [(s, s, s) for s in (256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192)]
@@ -43,19 +44,24 @@ def main():
     torch.backends.cuda.matmul.allow_tf32 = False
     side = torch.cuda.Stream()  # one stream for both libraries, so the torch events see this library's launches
     rows = []
+    lib = _lib.load()
     with torch.cuda.stream(side), sb.SB_Handle(0, stream=side.cuda_stream) as h:
         for (M, N, K) in SHAPES:
             a = torch.rand(M, K, device="cuda", dtype=dt) * 7 - 2
             b = torch.rand(K, N, device="cuda", dtype=dt) * 7 - 2
             c = torch.empty(M, N, device="cuda", dtype=dt)
-            reps = max(3, min(50, int(2e11 / (2.0 * M * N * K))))
+            reps = max(3, min(200, int(2e11 / (2.0 * M * N * K))))
             ms_v = time_ms(lambda: torch.matmul(a, b, out=c), torch.cuda.synchronize, reps)
             # the same memory problem in column-major terms: C^T (N x M) = B^T (N x K) * A^T (K x M)
             a_o = DeviceBuffer.from_pointer(b.data_ptr(), np_name, K * N, b)
             b_o = DeviceBuffer.from_pointer(a.data_ptr(), np_name, M * K, a)
             c_o = DeviceBuffer.from_pointer(c.data_ptr(), np_name, M * N, c)
-            ms_o = time_ms(lambda: sb._gemm(h, "n", "n", N, M, K, 1.0, a_o, N, b_o, K, 0.0, c_o, N),
-                           torch.cuda.synchronize, reps)
+            # straight through the C ABI: the Python mirror records an event per call, which at 20 us per
+            # launch makes the host the bottleneck and the comparison a comparison of launch paths
+            fn = lib.sbamd_sgemm if name == "f32" else lib.sbamd_dgemm
+            sc = C.c_float if name == "f32" else C.c_double
+            args = (h._h, b"n", b"n", N, M, K, sc(1.0), a_o.ptr, N, b_o.ptr, K, sc(0.0), c_o.ptr, N)
+            ms_o = time_ms(lambda: fn(*args), torch.cuda.synchronize, reps)
             tf = lambda ms: 2.0 * M * N * K / ms / 1e9
             depth = h.last_splitk()[0]
             rows.append((ms_o / ms_v, M, N, K, ms_o, ms_v, h.last_kernel(), depth))

@@ -53,10 +53,16 @@ def model(p, dtype, tile, depth, m, n, k):
 
 def main(path):
     data = []
+    fused_rows = []  # both K halves in one workgroup: fitted afterwards as a factor on the model of two resident workgroups
     auto = {}
-    for dt, ta, tb, m, k, n, bs, kern, tile, depth, ms in csv.reader(open(path)):
+    for row in csv.reader(open(path)):
+        dt, ta, tb, m, k, n, bs, kern, tile, depth, ms = row[:11]
+        fused = len(row) > 11 and row[11] == "1"
         m, k, n, kern, tile, depth = int(m), int(k), int(n), int(kern), int(tile), int(depth)
         us = float(ms) * 1e3
+        if fused:
+            fused_rows.append((dt, tile, m, n, k, us))
+            continue
         if kern == 0:
             auto[(m, n, k)] = us
             continue
@@ -97,6 +103,25 @@ def main(path):
         regrets.sort()
         print(f"margin {margin}: regret median {regrets[len(regrets)//2]:.3f}, 90th pct "
               f"{regrets[int(len(regrets)*0.9)]:.3f}, max {regrets[-1]:.3f}")
+    # halves_factor of gemm_dispatch.hpp (estimate_us with fused = true): measured time of the fused launch
+    # over the model's time for the two sets as two resident workgroups per tile, where the planner may use it
+    for tile in (1, 2):
+        ratios = []
+        for dt, t, m, n, k, us in fused_rows:
+            bm, bn, occ = TILES[t]
+            tiles = math.ceil(m / bm) * math.ceil(n / bn)
+            if t != tile or tiles * 2 > CUS * occ or k < 512:
+                continue
+            busiest = math.ceil(tiles / CUS) * 2
+            full, rem = divmod(busiest, occ)
+            bk = bk_of(t, dt)
+            k_chunk = bk * math.ceil(k / (bk * 2))
+            per_k = p["per_k"][t]
+            base = k_chunk * (full * per_k[occ - 1] + (per_k[rem - 1] if rem else 0.0))
+            ratios.append((us - p["t_single"]) / base)
+        if ratios:
+            ratios.sort()
+            print(f"halves_factor tile {tile}: median {ratios[len(ratios)//2]:.3f} (min {ratios[0]:.3f}, max {ratios[-1]:.3f}, n={len(ratios)})")
     now = sorted(auto[s] / min(c[6] for c in by[s]) for s in by if s in auto)
     print(f"library as measured: regret median {now[len(now)//2]:.3f}, 90th pct {now[int(len(now)*0.9)]:.3f}, max {now[-1]:.3f}")
 
