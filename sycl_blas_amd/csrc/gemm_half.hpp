@@ -70,7 +70,7 @@ struct GemmArgs16 {
   int64_t stride_a, stride_b, stride_c;
   int32_t batch;
   int32_t tiles_m, tiles_n;
-  int32_t vec_a, vec_b;
+  int32_t vec_a, vec_b;  // 16-byte aligned operand, leading dimension and batch stride (the direct-to-LDS kernel needs it)
   float alpha, beta;
   int32_t beta_zero;
   // K cut (register-staged kernels only): slice z covers k in [z*k_chunk, (z+1)*k_chunk)
@@ -93,10 +93,14 @@ struct TileLoader16 {
 
   u16x8 reg[NV];
 
-  // 16-byte loads.  Tiles that hang over the matrix edge use them too: a vector whose M/N
-  // index lies past the edge is pointed at the last valid row (K-contiguous operand) or the
-  // last valid vector (M/N-contiguous operand; the caller guarantees mn_lim % 8 == 0 there,
-  // so no vector straddles the edge).  What it loads only feeds C elements never stored.
+  // 16-byte loads of any alignment (global memory takes a misaligned vector; the type below tells the
+  // compiler so).  EDGE: the tile hangs over the matrix edge.  K-contiguous operand: a row past the edge is
+  // pointed at the last valid row.  M/N-contiguous operand: a vector that ends past the edge fetches the
+  // last valid vector instead (the matrix must hold one: mn_lim >= 8); store<true> puts the elements of the
+  // one vector that straddles the edge where they belong.  What the other clamped positions hold only feeds
+  // C elements that are never stored.  The caller guarantees a whole K step (k0 + BK <= k_end).
+  typedef u16x8 u16x8_any __attribute__((aligned(2)));
+  template <bool EDGE>
   __device__ inline void load_fast(const uint16_t* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim, int64_t k0,
                                    int tid) {
 #pragma unroll
@@ -104,17 +108,15 @@ struct TileLoader16 {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
-      const uint16_t* p;
       if (KMAJOR) {
         int64_t mn = mn0 + row;
-        mn = mn < mn_lim ? mn : mn_lim - 1;
-        p = x + (k0 + col) + mn * ld;
+        if (EDGE) mn = mn < mn_lim ? mn : mn_lim - 1;
+        reg[i] = *reinterpret_cast<const u16x8_any*>(x + (k0 + col) + mn * ld);
       } else {
         int64_t mn = mn0 + col;
-        mn = mn < mn_lim ? mn : mn_lim - V;
-        p = x + mn + (k0 + row) * ld;
+        if (EDGE) mn = mn + V <= mn_lim ? mn : mn_lim - V;
+        reg[i] = *reinterpret_cast<const u16x8_any*>(x + mn + (k0 + row) * ld);
       }
-      reg[i] = *reinterpret_cast<const u16x8*>(p);
     }
   }
 
@@ -140,13 +142,25 @@ struct TileLoader16 {
     }
   }
 
-  __device__ inline void store(SBAMD_LDS uint16_t* lds, int tid) const {
+  // EDGE: the registers come from load_fast<true>.  The vector of an M/N-contiguous operand that straddles
+  // the matrix edge holds the last 8 valid elements, i.e. it starts 8 - (valid elements of the vector)
+  // positions early: its elements are stored one by one at their own columns (the leading ones land on what
+  // the neighbouring vector stores there too -- the same values).  tile_valid = mn_lim - mn0.
+  template <bool EDGE = false>
+  __device__ inline void store(SBAMD_LDS uint16_t* lds, int tid, int tile_valid = BMN) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * NT;
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
-      *reinterpret_cast<SBAMD_LDS u16x8*>(lds + row * S + col) = reg[i];
+      if (EDGE && !KMAJOR && col < tile_valid && col + V > tile_valid) {
+        const int first = tile_valid - V;  // tile-relative column of reg[i][0]; negative in a tile narrower than a vector
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (first + e >= 0) lds[row * S + first + e] = reg[i][e];
+      } else {
+        *reinterpret_cast<SBAMD_LDS u16x8*>(lds + row * S + col) = reg[i];
+      }
     }
   }
 
@@ -173,7 +187,9 @@ struct TileLoader16 {
 };
 
 template <typename Tag, typename TOut, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
-__global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs16<TOut> g) {
+// Two wavefronts per SIMD (256 registers): two 128 x 128 workgroups share a compute unit and cover each other's
+// barriers; the gather at ragged edges may spill for it, the interior path does not.
+__global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_kernel(const GemmArgs16<TOut> g) {
   constexpr int NT = WM * WN * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 32, NI = WTN / 32;
@@ -222,35 +238,50 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
   LoadA la;
   LoadB lb;
   const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
-  const bool clampable = (TA || g.m % 8 == 0) && (!TB || g.n % 8 == 0);
-  const bool fast = (interior || clampable) && g.vec_a && g.vec_b;
   const int nk = k_end > k_begin ? int((k_end - k_begin + BK - 1) / BK) : 0;
   const int frag_mn = lane & 31, frag_h = lane >> 5;
   const int a_row = wm * WTM + frag_mn;
 
-  auto load_tile = [&](int kt) {
+  // How a tile's operands travel: whole vectors (interior tile), whole vectors clamped at the matrix edge, or
+  // element loads (K tail; a matrix narrower than one vector along a contiguous M / N).
+  enum { VEC = 0, VEC_EDGE = 1, ELEMENTS = 2 };
+  const bool vectors_fit = (TA || g.m >= 8) && (!TB || g.n >= 8);
+  const int valid_m = int(g.m - m0 < BM ? g.m - m0 : BM), valid_n = int(g.n - n0 < BN ? g.n - n0 : BN);
+  auto load_tile = [&](int kt) -> int {
     const int64_t k0 = k_begin + int64_t(kt) * BK;
-    if (fast && k0 + BK <= k_end) {
-      la.load_fast(a, g.lda, m0, g.m, k0, tid);
-      lb.load_fast(b, g.ldb, n0, g.n, k0, tid);
+    if (k0 + BK <= k_end && interior) {
+      la.template load_fast<false>(a, g.lda, m0, g.m, k0, tid);
+      lb.template load_fast<false>(b, g.ldb, n0, g.n, k0, tid);
+      return VEC;
+    }
+    if (k0 + BK <= k_end && vectors_fit) {
+      la.template load_fast<true>(a, g.lda, m0, g.m, k0, tid);
+      lb.template load_fast<true>(b, g.ldb, n0, g.n, k0, tid);
+      return VEC_EDGE;
+    }
+    la.load_edge(a, g.lda, m0, g.m, k0, k_end, tid);
+    lb.load_edge(b, g.ldb, n0, g.n, k0, k_end, tid);
+    return ELEMENTS;
+  };
+  auto store_tile = [&](SBAMD_LDS uint16_t* st, int how) {
+    if (how == VEC_EDGE) {
+      la.template store<true>(st, tid, valid_m);
+      lb.template store<true>(st + A_ELEMS, tid, valid_n);
     } else {
-      la.load_edge(a, g.lda, m0, g.m, k0, k_end, tid);
-      lb.load_edge(b, g.ldb, n0, g.n, k0, k_end, tid);
+      la.store(st, tid);
+      lb.store(st + A_ELEMS, tid);
     }
   };
 
-  if (nk > 0) {
-    load_tile(0);
-    la.store(smem, tid);
-    lb.store(smem + A_ELEMS, tid);
-  }
+  if (nk > 0) store_tile(smem, load_tile(0));
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const SBAMD_LDS uint16_t* as = smem + (kt & 1) * STAGE;
     const SBAMD_LDS uint16_t* bs = as + A_ELEMS;
     const bool more = kt + 1 < nk;
-    if (more) load_tile(kt + 1);
+    int how = VEC;
+    if (more) how = load_tile(kt + 1);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       u16x8 fa[MI], fb[NI];
@@ -264,11 +295,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_mfma16_kernel(const GemmArgs
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = Mfma16<Tag>::mma(fb[j], fa[i], acc[i][j]);
     }
-    if (more) {
-      SBAMD_LDS uint16_t* nxt = smem + ((kt + 1) & 1) * STAGE;
-      la.store(nxt, tid);
-      lb.store(nxt + A_ELEMS, tid);
-    }
+    if (more) store_tile(smem + ((kt + 1) & 1) * STAGE, how);
     __syncthreads();
   }
 

@@ -148,6 +148,9 @@ def test_both_tile_families(sb_handle, pair, family):
     for (m, n, k), ta, tb in itertools.product([(1, 1, 1), (129, 127, 70), (256, 128, 192), (200, 260, 133)], "nt", "nt"):
         run_case(sb_handle, pair, m, n, k, ta, tb, 1.5, 0.5, family=fam)
         run_case(sb_handle, pair, m, n, k, ta, tb, -2.0, 0.0, ldm=2, offset=8, family=fam)
+        # odd leading dimensions behind an odd offset: every 16-byte vector of the operands is misaligned, and
+        # the vectors that end past the matrix edge are gathered element by element
+        run_case(sb_handle, pair, m, n, k, ta, tb, 1.0, 1.0, offset=3, family=fam)
 
 
 @pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")

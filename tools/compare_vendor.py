@@ -1,7 +1,9 @@
 """Yardstick sweep (not part of the library or its tests): this library against the vendor GEMM behind
 torch.matmul on the same GPU, same memory problem, over a list of shapes -- to find the shapes
 where a kernel or the planner leaves the most on the table.
-Usage: python tools/compare_vendor.py [f32|f64] [--csv out.csv]"""
+Usage: python tools/compare_vendor.py [f32|f64|bf16|f16] [--csv out.csv]
+(bf16: bfloat16 operands, float result on this side -- sbamd_bsgemm -- against the vendor's bfloat16 result;
+f16: half operands and result on both sides.)"""
 import ctypes as C
 import os
 import sys
@@ -38,8 +40,10 @@ def time_ms(fn, sync, reps):
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "f32"
-    dt = {"f32": torch.float32, "f64": torch.float64}[name]
-    np_name = {"f32": "float32", "f64": "float64"}[name]
+    dt = {"f32": torch.float32, "f64": torch.float64, "bf16": torch.bfloat16, "f16": torch.float16}[name]
+    np_name = {"f32": "float32", "f64": "float64", "bf16": "bfloat16", "f16": "float16"}[name]
+    out_dt = torch.float32 if name == "bf16" else dt
+    out_np = "float32" if name == "bf16" else np_name
     csv = open(sys.argv[sys.argv.index("--csv") + 1], "w") if "--csv" in sys.argv else None
     torch.backends.cuda.matmul.allow_tf32 = False
     side = torch.cuda.Stream()  # one stream for both libraries, so the torch events see this library's launches
@@ -47,19 +51,20 @@ def main():
     lib = _lib.load()
     with torch.cuda.stream(side), sb.SB_Handle(0, stream=side.cuda_stream) as h:
         for (M, N, K) in SHAPES:
-            a = torch.rand(M, K, device="cuda", dtype=dt) * 7 - 2
-            b = torch.rand(K, N, device="cuda", dtype=dt) * 7 - 2
+            a = (torch.rand(M, K, device="cuda", dtype=torch.float32) * 7 - 2).to(dt)
+            b = (torch.rand(K, N, device="cuda", dtype=torch.float32) * 7 - 2).to(dt)
             c = torch.empty(M, N, device="cuda", dtype=dt)
+            c_ours = c if out_dt == dt else torch.empty(M, N, device="cuda", dtype=out_dt)
             reps = max(3, min(200, int(2e11 / (2.0 * M * N * K))))
             ms_v = time_ms(lambda: torch.matmul(a, b, out=c), torch.cuda.synchronize, reps)
             # the same memory problem in column-major terms: C^T (N x M) = B^T (N x K) * A^T (K x M)
             a_o = DeviceBuffer.from_pointer(b.data_ptr(), np_name, K * N, b)
             b_o = DeviceBuffer.from_pointer(a.data_ptr(), np_name, M * K, a)
-            c_o = DeviceBuffer.from_pointer(c.data_ptr(), np_name, M * N, c)
+            c_o = DeviceBuffer.from_pointer(c_ours.data_ptr(), out_np, M * N, c_ours)
             # straight through the C ABI: the Python mirror records an event per call, which at 20 us per
             # launch makes the host the bottleneck and the comparison a comparison of launch paths
-            fn = lib.sbamd_sgemm if name == "f32" else lib.sbamd_dgemm
-            sc = C.c_float if name == "f32" else C.c_double
+            fn = {"f32": lib.sbamd_sgemm, "f64": lib.sbamd_dgemm, "bf16": lib.sbamd_bsgemm, "f16": lib.sbamd_hgemm}[name]
+            sc = C.c_double if name == "f64" else C.c_float
             args = (h._h, b"n", b"n", N, M, K, sc(1.0), a_o.ptr, N, b_o.ptr, K, sc(0.0), c_o.ptr, N)
             ms_o = time_ms(lambda: fn(*args), torch.cuda.synchronize, reps)
             tf = lambda ms: 2.0 * M * N * K / ms / 1e9
@@ -70,7 +75,7 @@ def main():
             print(line, flush=True)
             if csv:
                 csv.write(f"{name},{M},{N},{K},{ms_o * 1e3:.2f},{ms_v * 1e3:.2f},{h.last_kernel()},{depth}\n")
-            del a, b, c
+            del a, b, c, c_ours
     rows.sort(reverse=True)
     print("worst five (time ratio ours / vendor):")
     for r in rows[:5]:

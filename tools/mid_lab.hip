@@ -58,7 +58,30 @@ int run(const char* name, int n, int reps = 5) {
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'h') {  // the biggest tile at the headline size
+    for (int round = 0; round < 2; ++round)
+      if (run<float, 256, 256, 16, 2, 4, 2>("f32 256x256x16 (2x4 waves)", 8192, 5)) return 1;
+#ifdef LAB_FOUR_WAVES
+      if (run<float, 256, 256, 16, 2, 2, 1>("f32 256x256x16 (2x2 waves of 128x128)", 8192, 5)) return 1;
+      if (run<float, 256, 256, 8, 2, 2, 1>("f32 256x256x8 (2x2 waves of 128x128)", 8192, 5)) return 1;
+#endif
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'q') {  // 96-row tiles against 128 x 128 where the tile count quantises badly
+    for (int round = 0; round < 2; ++round)
+      for (int n : {1536, 3072}) {
+        const int reps = n == 1536 ? 100 : 20;
+        if (run<float, 128, 128, 32, 4, 2, 2>("f32 128x128x32 (8 waves) occ2", n, reps)) return 1;
+        if (run<float, 96, 128, 32, 1, 4, 1>("f32 96x128x32 (1x4 waves) occ1", n, reps)) return 1;
+        if (run<float, 96, 128, 32, 1, 4, 2>("f32 96x128x32 (1x4 waves) occ2", n, reps)) return 1;
+        if (run<float, 192, 128, 32, 2, 4, 2>("f32 192x128x32 (2x4 waves) occ2", n, reps)) return 1;
+        if (run<double, 128, 128, 16, 2, 2, 1>("f64 128x128x16 (4 waves) occ1", n, reps / 2)) return 1;
+        if (run<double, 96, 128, 16, 1, 4, 1>("f64 96x128x16 (1x4 waves) occ1", n, reps / 2)) return 1;
+        if (run<double, 96, 128, 16, 1, 4, 2>("f64 96x128x16 (1x4 waves) occ2", n, reps / 2)) return 1;
+      }
+    return 0;
+  }
   for (int round = 0; round < 2; ++round) {
     if (run<float, 64, 64, 32, 2, 2, 1>("f32 64x64x32 occ1", 1024, 200)) return 1;
     if (run<float, 128, 128, 32, 4, 2, 2>("f32 128x128x32 (8 waves)", 2048, 50)) return 1;
