@@ -57,7 +57,7 @@ struct GemmArgs {
   int64_t k_chunk;                       // K range of one split-K slice
   int64_t slice_stride;                  // elements between slices of the cube
   int32_t tiles_m, tiles_n;
-  int32_t vec_a, vec_b;                  // 16-byte loads are legal for A / B
+  int32_t vec_a, vec_b;                  // A / B: base, leading dimension and batch stride are 16-byte aligned (direct-to-LDS staging needs it)
   T alpha, beta;
   int32_t beta_zero;                     // never read C
   int32_t group_m;                       // rows of tiles per band of the workgroup -> tile map (0: the default)
@@ -144,6 +144,8 @@ struct TileLoader {
   static constexpr int NWRITE = NV * ((KMAJOR && V == 4) ? 2 : 1);  // LDS store instructions per tile
 
   T reg[NV][V];
+  // Global memory takes a 16-byte load at element alignment; this type tells the compiler so.
+  typedef typename M::vec_t vec_any_t __attribute__((aligned(sizeof(T))));
 
   // Interior tile, whole K step, 16-byte aligned: straight-line vector loads
   // through per-thread pointers that are set up once per workgroup and then
@@ -153,10 +155,10 @@ struct TileLoader {
 
   //
   // Tiles that hang over the matrix edge use the same path: a vector whose M/N
-  // index lies past the edge is pointed at the last valid row (K-major) or the
-  // last valid vector (MN-major; the caller guarantees mn_lim % V == 0 there, so
-  // no vector straddles the edge).  What it loads only feeds C elements that are
-  // never stored.
+  // index lies past the edge is pointed at the last valid row (K-major) or, when it
+  // ends past the edge, at the last valid vector (MN-major; needs mn_lim >= V).  What
+  // it loads only feeds C elements that are never stored -- except the one vector that
+  // straddles the edge when mn_lim % V != 0: store_ragged puts its elements in place.
   __device__ inline void init_fast(const T* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim, int64_t k0,
                                    int tid) {
 #pragma unroll
@@ -170,7 +172,7 @@ struct TileLoader {
         ptr[i] = x + (k0 + col) + mn * ld;
       } else {
         int64_t mn = mn0 + col;
-        mn = mn < mn_lim ? mn : mn_lim - V;
+        mn = mn + V <= mn_lim ? mn : mn_lim - V;
         ptr[i] = x + mn + (k0 + row) * ld;
       }
     }
@@ -182,7 +184,7 @@ struct TileLoader {
     const int64_t step = DIR * (KMAJOR ? int64_t(BK) : int64_t(BK) * ld);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(ptr[i]);
+      const typename M::vec_t vv = *reinterpret_cast<const vec_any_t*>(ptr[i]);
 #pragma unroll
       for (int e = 0; e < V; ++e) reg[i][e] = vv[e];
       ptr[i] += step;
@@ -193,7 +195,7 @@ struct TileLoader {
   // matrix instructions (store vector i, then request its successor into the registers just freed).
   template <int DIR = 1>
   __device__ inline void load_one(int64_t ld, int i) {
-    const typename M::vec_t vv = *reinterpret_cast<const typename M::vec_t*>(ptr[i]);
+    const typename M::vec_t vv = *reinterpret_cast<const vec_any_t*>(ptr[i]);
 #pragma unroll
     for (int e = 0; e < V; ++e) reg[i][e] = vv[e];
     ptr[i] += DIR * (KMAJOR ? int64_t(BK) : int64_t(BK) * ld);
@@ -225,6 +227,27 @@ struct TileLoader {
   __device__ inline void store(SBAMD_LDS T* lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) store_one(lds, tid, i);
+  }
+
+  // store() for a tile whose M/N extent ends inside a vector (tile_valid = mn_lim - mn0, not a multiple
+  // of V): the vector that straddles the edge was fetched from the last valid vector, V - (its valid
+  // elements) positions early, and its elements go to their own columns one by one (the leading ones land
+  // on what the neighbouring vector stores there too -- the same values).
+  __device__ inline void store_ragged(SBAMD_LDS T* lds, int tid, int tile_valid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / PER_ROW;
+      const int col = (v % PER_ROW) * V;
+      if (!KMAJOR && col < tile_valid && col + V > tile_valid) {
+        const int first = tile_valid - V;  // column of reg[i][0]; negative in a tile narrower than a vector
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (first + e >= 0) lds[row * S + first + e] = reg[i][e];
+      } else {
+        store_one(lds, tid, i);
+      }
+    }
   }
 
   __device__ inline void store_one(SBAMD_LDS T* lds, int tid, int i) const {
@@ -734,7 +757,55 @@ struct GemmBody {
     }
   }
 
-  // ---- simple path (edge tiles, unaligned operands): element loads, one
+  // ---- edge tiles whose M (N) extent ends inside a 16-byte vector of a contiguous-M (N) operand: the
+  // vector loads of the pipelined path with the straddling vector put in place by store_ragged, in the
+  // simple loop below (one barrier per K step, loads of the next tile issued before the compute).  The K
+  // tail is one step of element loads.  Needs m >= V (n >= V) for such an operand.
+  __device__ inline void run_ragged(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
+                                    int64_t k_begin, int64_t k_end, SBAMD_LDS T* smem, int tid, int a_mn,
+                                    int b_mn) {
+    const int lane = tid & 63;
+    const int64_t klen = k_end > k_begin ? k_end - k_begin : 0;
+    const int nk = int((klen + BK - 1) / BK);
+    const int nfull = int(klen / BK);
+    if (nk == 0) return;
+    const int valid_m = int(g.m - m0 < BM ? g.m - m0 : BM);
+    const int valid_n = int(g.n - n0 < BN ? g.n - n0 : BN);
+    la.init_fast(a, g.lda, m0, g.m, k_begin, tid);
+    lb.init_fast(b, g.ldb, n0, g.n, k_begin, tid);
+    auto load = [&](int kt) {
+      if (kt < nfull) {
+        la.load_fast(g.lda);
+        lb.load_fast(g.ldb);
+      } else {
+        la.load_edge(a, g.lda, m0, g.m, k_begin + int64_t(kt) * BK, k_end, tid);
+        lb.load_edge(b, g.ldb, n0, g.n, k_begin + int64_t(kt) * BK, k_end, tid);
+      }
+    };
+    auto store = [&](int kt) {
+      SBAMD_LDS T* st = smem + (kt & 1) * K::STAGE_ELEMS;
+      if (kt < nfull) {
+        la.store_ragged(st, tid, valid_m);
+        lb.store_ragged(st + K::A_ELEMS, tid, valid_n);
+      } else {
+        la.store(st, tid);
+        lb.store(st + K::A_ELEMS, tid);
+      }
+    };
+    load(0);
+    store(0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) {
+      load(kt + 1);
+      compute<0>(smem + (kt & 1) * K::STAGE_ELEMS, smem + (kt & 1) * K::STAGE_ELEMS + K::A_ELEMS, a_mn, b_mn, lane);
+      store(kt + 1);
+      __syncthreads();
+    }
+    compute<0>(smem + (kt & 1) * K::STAGE_ELEMS, smem + (kt & 1) * K::STAGE_ELEMS + K::A_ELEMS, a_mn, b_mn, lane);
+  }
+
+  // ---- simple path (K ranges shorter than a K step, matrices narrower than a vector): element loads, one
   // barrier per K step, loads of the next tile issued before the compute.
   __device__ inline void run_edge(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0,
                                   int64_t k_begin, int64_t k_end, SBAMD_LDS T* smem, int tid, int a_mn,
@@ -815,8 +886,11 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   // vector along M (N) could straddle it.
   const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
   const bool clampable = (TA || g.m % M::V == 0) && (!TB || g.n % M::V == 0);
-  if ((interior || clampable) && g.vec_a && g.vec_b && k_end - k_begin >= BK) {
+  const bool vectors_fit = (TA || g.m >= M::V) && (!TB || g.n >= M::V);
+  if ((interior || clampable) && k_end - k_begin >= BK) {
     body.run_pipelined(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
+  } else if (!interior && !clampable && vectors_fit) {
+    body.run_ragged(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
   } else {
     body.run_edge(g, a, b, m0, n0, k_begin, k_end, smem, tid, a_mn, b_mn);
   }
@@ -903,8 +977,11 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
   SBAMD_LDS T* mine = smem + half * (2 * K::STAGE_ELEMS);
   const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);
   const bool clampable = (TA || g.m % M::V == 0) && (!TB || g.n % M::V == 0);
-  if ((interior || clampable) && g.vec_a && g.vec_b) {
+  const bool vectors_fit = (TA || g.m >= M::V) && (!TB || g.n >= M::V);
+  if (interior || clampable) {
     body.run_pipelined(g, a, b, m0, n0, k_begin, k_end, mine, tid, a_mn, b_mn);
+  } else if (vectors_fit) {
+    body.run_ragged(g, a, b, m0, n0, k_begin, k_end, mine, tid, a_mn, b_mn);
   } else {
     body.run_edge(g, a, b, m0, n0, k_begin, k_end, mine, tid, a_mn, b_mn);
   }
