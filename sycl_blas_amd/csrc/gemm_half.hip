@@ -1,4 +1,6 @@
 // 16-bit storage back end: half -> half, half -> float, bfloat16 -> float.
+#include <cmath>
+
 #include "gemm_dispatch.hpp"
 #include "gemm_half.hpp"
 #include "gemm_half_dma.hpp"
@@ -58,6 +60,26 @@ hipError_t launch16_dma(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream
     return tb ? launch16_dma_one<Tag, TOut, true, true>(g, stream) : launch16_dma_one<Tag, TOut, true, false>(g, stream);
   }
   return tb ? launch16_dma_one<Tag, TOut, false, true>(g, stream) : launch16_dma_one<Tag, TOut, false, false>(g, stream);
+}
+
+// Which tile family for a 16-bit GEMM: estimated microseconds per family from the costs per unit of K that
+// a compute unit showed on MI355X (bf16 NN sweep, tools/sweep16.py), cheapest wins.
+//   256 x 256 ring kernel, one workgroup per unit: 0.027 us with every unit busy, 0.018 with few (the clock
+//     gives back under load), so a round of r * cus tiles costs 0.018 + 0.009 r^2;
+//   128 x 128, two workgroups per unit: 0.0193 us for a resident pair, 0.0141 for a workgroup alone;
+//   64 x 64: 0.0079 us alone, 0.0043 per workgroup from four per unit on.
+// 3072^3 (144 big tiles, 56 % of the units) runs 62.7 us on the big tile against 102 on 128 x 128.
+inline int pick_family16(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, bool ring_ok) {
+  auto tiles = [&](int64_t b) { return double(ceil_div(m, b) * ceil_div(n, b) * batch); };
+  const double kk = double(k);
+  const double q256 = tiles(256) / cus, q128 = std::ceil(tiles(128) / cus), q64 = std::ceil(tiles(64) / cus);
+  const double whole = std::floor(q256), part = q256 - whole;
+  const double t_huge = 5.0 + kk * (whole * 0.027 + (part > 0.0 ? 0.018 + 0.009 * part * part : 0.0));
+  const double t_large = 5.0 + kk * (std::floor(q128 / 2.0) * 0.0193 + (std::fmod(q128, 2.0) != 0.0 ? 0.0141 : 0.0));
+  const double per64 = q64 <= 1.0 ? 0.0079 : q64 <= 2.0 ? 0.0105 : q64 <= 3.0 ? 0.0147 : 0.0043 * q64;
+  const double t_small = 5.0 + kk * per64;
+  if (ring_ok && t_huge <= t_large && t_huge <= t_small) return SBAMD_KERNEL_HUGE;
+  return t_large <= t_small ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
 }
 
 inline bool vec16_ok(const uint16_t* p, int64_t ld, int64_t stride, int64_t batch) {
@@ -163,19 +185,13 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
   if (p.interleaved) return run16_interleaved<Tag, TOut>(h, p, g, alpha, beta);
 
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
-  // The direct-to-LDS 256x256 kernel needs whole K steps, 16-byte vectors and no
+  // The direct-to-LDS 256x256 kernel needs at least one whole K step, 16-byte vectors and no
   // vector straddling the matrix edge.
-  const bool dma_ok = g.vec_a && g.vec_b && p.k >= RING_BK && p.k % RING_BK == 0 && (p.ta || p.m % 8 == 0) &&
-                      (!p.tb || p.n % 8 == 0);
+  const bool dma_ok = g.vec_a && g.vec_b && p.k >= RING_BK && (p.ta || p.m % 8 == 0) && (!p.tb || p.n % 8 == 0);
   int family = h->kernel_override;
   if (family == SBAMD_KERNEL_HUGE && !dma_ok) family = SBAMD_KERNEL_AUTO;
   if (family != SBAMD_KERNEL_LARGE && family != SBAMD_KERNEL_SMALL && family != SBAMD_KERNEL_HUGE) {
-    auto fits = [&](int bm, int bn) {
-      const int64_t tm = ceil_div(p.m, bm), tn = ceil_div(p.n, bn);
-      const double fill = double(p.m) * double(p.n) / (double(tm * bm) * double(tn * bn));
-      return fill >= 0.75 && tm * tn * p.batch >= cus;
-    };
-    family = (dma_ok && fits(256, 256)) ? SBAMD_KERNEL_HUGE : fits(128, 128) ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
+    family = pick_family16(p.m, p.n, p.k, p.batch, cus, dma_ok);
   }
   // Few 64x64 tiles and a long K (thin transformer shapes: 48 x 4096 x 4096, 224 x 1024 x 32768):
   // cut K over extra workgroups of the 64x64 kernel, fp32 partial sums in the handle's

@@ -13,9 +13,10 @@
 //     the LDS image is linear and the bank-conflict-free arrangement is produced by
 //     permuting WHICH 16-byte piece of global memory each lane fetches; fragment
 //     reads apply the same permutation (an involution) to their address.
-// Requirements (checked by the launcher): K a multiple of 32, 16-byte aligned
-// operands with leading dimensions that are multiples of 8, and M (N) a multiple
-// of 8 when it is the contiguous index of A (B).  Tiles that hang over the matrix
+// Requirements (checked by the launcher): K >= 32 (a remainder of K modulo 32 is one
+// zero-padded, register-staged tile behind the ring), 16-byte aligned operands with
+// leading dimensions that are multiples of 8, and M (N) a multiple of 8 when it is the
+// contiguous index of A (B).  Tiles that hang over the matrix
 // edge fetch clamped rows/columns, which only feed C elements that are never stored.
 #pragma once
 
@@ -104,6 +105,32 @@ struct RingOperand {
     const int64_t step = KMAJOR ? int64_t(RING_BK) : int64_t(RING_BK) * ld;
     src[0] += step;
     src[1] += step;
+  }
+
+  // Piece I of the K tail (k_rem = 1 .. 31 valid k behind the last whole K step, which is where the
+  // pointers stand after the main loop): through registers, zeros past the end of K.
+  template <int I>
+  __device__ inline u16x8 load_tail(int k_rem, int tid) const {
+    const int L = I * DMA_NT + tid;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (KMAJOR) {
+      const int row = L >> 2;
+      const int kl = ((L & 3) ^ ring_swizzle_k<SHAPE>(row)) * 8;
+      if (kl + 8 <= k_rem) {
+        v = *reinterpret_cast<const u16x8*>(src[I]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (kl + e < k_rem) v[e] = src[I][e];
+      }
+    } else {
+      if ((L >> 5) < k_rem) v = *reinterpret_cast<const u16x8*>(src[I]);
+    }
+    return v;
+  }
+  template <int I>
+  __device__ static inline void store_tail(SBAMD_LDS unsigned char* lds, int tid, u16x8 v) {
+    *reinterpret_cast<SBAMD_LDS u16x8*>(lds + (I * DMA_NT + tid) * 16) = v;
   }
 
   // Fragment of k-step S (16 k) for the 32 rows starting at tile-relative mn0.
@@ -295,6 +322,38 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
   for (; t + RING_AHEAD < nk; ++t) step(stage_ptr(t), stage_ptr(t + 1), stage_ptr(t + RING_AHEAD), yes{}, yes{});
   for (; t + 1 < nk; ++t) step(stage_ptr(t), stage_ptr(t + 1), stage_ptr(t + RING_AHEAD), no{}, yes{});
   if (t < nk) step(stage_ptr(t), stage_ptr(t + 1), stage_ptr(t + RING_AHEAD), no{}, no{});
+
+  // K tail (k % 32 valid k): one more tile, zero-padded, staged through registers into stage 0 once every
+  // wavefront has finished the last ring step; the zeros add nothing to the sums.
+  const int k_rem = int(g.k - int64_t(nk) * RING_BK);
+  if (k_rem > 0) {
+    __syncthreads();
+    const u16x8 a0 = oa.template load_tail<0>(k_rem, tid), a1 = oa.template load_tail<1>(k_rem, tid);
+    const u16x8 b0 = ob.template load_tail<0>(k_rem, tid), b1 = ob.template load_tail<1>(k_rem, tid);
+    OpA::template store_tail<0>(smem, tid, a0);
+    OpA::template store_tail<1>(smem, tid, a1);
+    OpB::template store_tail<0>(smem + RING_OPERAND_BYTES, tid, b0);
+    OpB::template store_tail<1>(smem + RING_OPERAND_BYTES, tid, b1);
+    __syncthreads();
+    auto tail_half = [&](auto s_tag) {
+      auto all = [&](auto u) { read_unit(u, s_tag, smem, fa[0], fb[0]); };
+      all(std::integral_constant<int, 0>{});
+      all(std::integral_constant<int, 1>{});
+      all(std::integral_constant<int, 2>{});
+      all(std::integral_constant<int, 3>{});
+      all(std::integral_constant<int, 4>{});
+      all(std::integral_constant<int, 5>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposing reads are not tracked by the compiler
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = Mfma16<Tag>::mma(fb[0][j], fa[0][i], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    tail_half(std::integral_constant<int, 0>{});
+    if (k_rem > 16) tail_half(std::integral_constant<int, 1>{});
+  }
 
   const bool read_c = !g.beta_zero;
   const int frag_mn = lane & 31, frag_h = lane >> 5;

@@ -159,14 +159,22 @@ def test_direct_to_lds_family(sb_handle, pair):
     # over both edges, fewer K steps than the ring is deep and many more, padded leading
     # dimensions and a 16-byte-aligned offset, every transpose combination.
     fam = _lib.KERNEL_HUGE
-    for (m, n, k), ta, tb in itertools.product([(256, 256, 32), (304, 520, 96), (512, 264, 160), (1000, 776, 256), (264, 256, 1024)],
+    # K tails (k % 32 != 0: one zero-padded tile behind the ring): shorter and longer than half a K step, behind
+    # one ring step and behind many.
+    for (m, n, k), ta, tb in itertools.product([(256, 256, 32), (304, 520, 96), (512, 264, 160), (1000, 776, 256), (264, 256, 1024),
+                                                (256, 256, 33), (304, 520, 100), (512, 264, 1007), (264, 520, 49), (256, 264, 40), (520, 256, 1016)],
                                                "nt", "nt"):
+        # a K tail makes the leading dimension of a K-contiguous operand odd: those fall back (16-byte rows needed)
+        def takes(ldm):
+            lda, ldb = (k if ta != "n" else m) * ldm, (n if tb != "n" else k) * ldm
+            return lda % 8 == 0 and ldb % 8 == 0
+
         run_case(sb_handle, pair, m, n, k, ta, tb, 1.5, 0.5, family=fam)
-        assert sb_handle.last_kernel() == fam
+        assert (sb_handle.last_kernel() == fam) == takes(1)
         run_case(sb_handle, pair, m, n, k, ta, tb, -2.0, 0.0, ldm=2, offset=8, family=fam)
-        assert sb_handle.last_kernel() == fam
-    # shapes it cannot take (K tail, odd M with M contiguous, unaligned offset) fall back to the other tiles
-    run_case(sb_handle, pair, 256, 256, 100, "n", "n", 1.0, 1.0, family=fam)
+        assert (sb_handle.last_kernel() == fam) == takes(2)
+    # shapes it cannot take (K shorter than a K step, odd M with M contiguous, unaligned offset) fall back to the other tiles
+    run_case(sb_handle, pair, 256, 256, 31, "n", "n", 1.0, 1.0, family=fam)
     assert sb_handle.last_kernel() != fam
     run_case(sb_handle, pair, 257, 256, 128, "n", "n", 1.0, 1.0, family=fam)
     assert sb_handle.last_kernel() != fam
