@@ -37,45 +37,54 @@ hipError_t launch16(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream) {
             : launch16_one<Tag, TOut, BM, BN, BK, WM, WN, false, false>(g, stream);
 }
 
-template <typename Tag, typename TOut, bool TA, bool TB>
+template <typename Tag, typename TOut, int BM, int BN, int WM, int WN, bool TA, bool TB>
 hipError_t launch16_dma_one(const GemmArgs16<TOut>& g, hipStream_t stream) {
-  auto kernel = gemm_mfma16_ring_kernel<Tag, TOut, TA, TB>;
+  auto kernel = gemm_mfma16_ring_kernel<Tag, TOut, TA, TB, 0, BM, BN, WM, WN>;
+  constexpr int lds = ring_lds_bytes(BM, BN);
+  static_assert(lds <= 160 * 1024, "the ring must fit the LDS");
   static PerDeviceOnce lds_limit;
   hipError_t e = lds_limit.run([&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               RING_LDS_BYTES);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   if (e != hipSuccess) return e;
   const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * g.batch;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(DMA_NT), RING_LDS_BYTES, stream, g);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WM * WN * 64), lds, stream, g);
   return hipGetLastError();
 }
 
-template <typename Tag, typename TOut>
+// The direct-to-LDS ring kernel: 256 x 256 tiles on 2 x 4 wavefronts or 128 x 128 on 2 x 2.
+template <typename Tag, typename TOut, int BM, int BN, int WM, int WN>
 hipError_t launch16_dma(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream) {
-  g.tiles_m = int32_t(ceil_div(g.m, DMA_BM));
-  g.tiles_n = int32_t(ceil_div(g.n, DMA_BN));
+  g.tiles_m = int32_t(ceil_div(g.m, BM));
+  g.tiles_n = int32_t(ceil_div(g.n, BN));
   if (ta) {
-    return tb ? launch16_dma_one<Tag, TOut, true, true>(g, stream) : launch16_dma_one<Tag, TOut, true, false>(g, stream);
+    return tb ? launch16_dma_one<Tag, TOut, BM, BN, WM, WN, true, true>(g, stream)
+              : launch16_dma_one<Tag, TOut, BM, BN, WM, WN, true, false>(g, stream);
   }
-  return tb ? launch16_dma_one<Tag, TOut, false, true>(g, stream) : launch16_dma_one<Tag, TOut, false, false>(g, stream);
+  return tb ? launch16_dma_one<Tag, TOut, BM, BN, WM, WN, false, true>(g, stream)
+            : launch16_dma_one<Tag, TOut, BM, BN, WM, WN, false, false>(g, stream);
 }
 
 // Which tile family for a 16-bit GEMM: estimated microseconds per family from the costs per unit of K that
 // a compute unit showed on MI355X (bf16 NN sweep, tools/sweep16.py), cheapest wins.
 //   256 x 256 ring kernel, one workgroup per unit: 0.027 us with every unit busy, 0.018 with few (the clock
 //     gives back under load), so a round of r * cus tiles costs 0.018 + 0.009 r^2;
-//   128 x 128, two workgroups per unit: 0.0193 us for a resident pair, 0.0141 for a workgroup alone;
+//   128 x 128 ring kernel, two workgroups per unit: 0.0088 us per tile a unit has to work through;
+//   128 x 128 register-staged (operands the ring kernel cannot take): 0.0193 us for a resident pair, 0.0141
+//     for a workgroup alone;
 //   64 x 64: 0.0079 us alone, 0.0043 per workgroup from four per unit on.
-// 3072^3 (144 big tiles, 56 % of the units) runs 62.7 us on the big tile against 102 on 128 x 128.
+// 3072^3 (144 big tiles, 56 % of the units) runs 65 us on the big tile against 81 on 128 x 128; 2304^3 40 us on
+// 128 x 128 against 49.
 inline int pick_family16(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, bool ring_ok) {
   auto tiles = [&](int64_t b) { return double(ceil_div(m, b) * ceil_div(n, b) * batch); };
   const double kk = double(k);
   const double q256 = tiles(256) / cus, q128 = std::ceil(tiles(128) / cus), q64 = std::ceil(tiles(64) / cus);
   const double whole = std::floor(q256), part = q256 - whole;
   const double t_huge = 5.0 + kk * (whole * 0.027 + (part > 0.0 ? 0.018 + 0.009 * part * part : 0.0));
-  const double t_large = 5.0 + kk * (std::floor(q128 / 2.0) * 0.0193 + (std::fmod(q128, 2.0) != 0.0 ? 0.0141 : 0.0));
+  const double t_large =
+      5.0 + kk * (ring_ok ? 0.0088 * q128
+                          : std::floor(q128 / 2.0) * 0.0193 + (std::fmod(q128, 2.0) != 0.0 ? 0.0141 : 0.0));
   const double per64 = q64 <= 1.0 ? 0.0079 : q64 <= 2.0 ? 0.0105 : q64 <= 3.0 ? 0.0147 : 0.0043 * q64;
   const double t_small = 5.0 + kk * per64;
   if (ring_ok && t_huge <= t_large && t_huge <= t_small) return SBAMD_KERNEL_HUGE;
@@ -201,7 +210,10 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
     int64_t depth = h->kernel_override == SBAMD_KERNEL_SPLITK && (h->kernel_param & 0xffff) > 0
                         ? (h->kernel_param & 0xffff)
                         : std::min<int64_t>(ceil_div(4 * int64_t(cus), tiles64), p.k / 128);
-    if (p.batch == 1 && (h->kernel_override == SBAMD_KERNEL_SPLITK || ((tiles64 * 2 <= cus && p.k >= 1024) || (tiles64 <= 2 * cus && p.k >= 2048))) && depth > 1) {
+    // ... unless the 128 x 128 ring kernel has tiles for half of the units: it then finishes first without
+    // the second launch (512 x 4096 x 4096: 34 us against 46 cut in two)
+    const bool ring_fills = dma_ok && ceil_div(p.m, 128) * ceil_div(p.n, 128) * 2 >= cus;
+    if (p.batch == 1 && (h->kernel_override == SBAMD_KERNEL_SPLITK || (!ring_fills && ((tiles64 * 2 <= cus && p.k >= 1024) || (tiles64 <= 2 * cus && p.k >= 2048)))) && depth > 1) {
       const int64_t k_chunk = 32 * ceil_div(p.k, 32 * depth);
       depth = ceil_div(p.k, k_chunk);
       if (depth > 1) {
@@ -233,8 +245,13 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
     if (h->kernel_override == SBAMD_KERNEL_SPLITK) family = SBAMD_KERNEL_SMALL;
   }
   h->last_kernel = family;
-  if (family == SBAMD_KERNEL_HUGE) return launch16_dma<Tag, TOut>(g, p.ta, p.tb, h->stream);
-  if (family == SBAMD_KERNEL_LARGE) return launch16<Tag, TOut, 128, 128, 64, 2, 2>(g, p.ta, p.tb, h->stream);
+  if (family == SBAMD_KERNEL_HUGE) return launch16_dma<Tag, TOut, DMA_BM, DMA_BN, 2, 4>(g, p.ta, p.tb, h->stream);
+  if (family == SBAMD_KERNEL_LARGE) {
+    // pinned with bit 0 of the parameter set: keep the register-staged kernel where the ring kernel would run
+    const bool keep_staged = h->kernel_override == SBAMD_KERNEL_LARGE && (h->kernel_param & 1);
+    if (dma_ok && !keep_staged) return launch16_dma<Tag, TOut, 128, 128, 2, 2>(g, p.ta, p.tb, h->stream);
+    return launch16<Tag, TOut, 128, 128, 64, 2, 2>(g, p.ta, p.tb, h->stream);
+  }
   return launch16<Tag, TOut, 64, 64, 32, 2, 2>(g, p.ta, p.tb, h->stream);
 }
 

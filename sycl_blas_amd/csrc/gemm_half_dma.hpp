@@ -1,14 +1,15 @@
-// 256 x 256 MFMA GEMM for 16-bit storage whose operand tiles go from global memory
-// straight into LDS (global_load_lds_dwordx4, no register staging) through a ring
-// of five LDS stages.
+// MFMA GEMM for 16-bit storage whose operand tiles go from global memory straight into
+// LDS (global_load_lds_dwordx4, no register staging) through a ring of five LDS stages:
+// 256 x 256 tiles on eight wavefronts (one workgroup per compute unit) and 128 x 128 tiles
+// on four (two workgroups per unit, for shapes with too few big tiles).
 //
 // Same arithmetic as gemm_mfma16_kernel (gemm_half.hpp): v_mfma_f32_32x32x16, fp32
 // accumulation in k order, one rounding at the end -- the two kernels agree bit for
 // bit.  What changes is the data movement, sized for one 8-wave workgroup per
 // compute unit:
-//   * each wave owns a 128 (M) x 64 (N) block of C: 6 fragment reads feed 8 matrix
-//     instructions per 16 k, a third of the LDS read traffic per flop of the 64 x 64
-//     wave tile (which runs the LDS at its limit);
+//   * in the big tile each wave owns a 128 (M) x 64 (N) block of C: 6 fragment reads feed 8
+//     matrix instructions per 16 k, a third of the LDS read traffic per flop of the 64 x 64
+//     wave tile (which runs the LDS at its limit; the 128 x 128 tile lives with that);
 //   * a load instruction writes 64 lanes x 16 bytes = 1 KiB of LDS contiguously, so
 //     the LDS image is linear and the bank-conflict-free arrangement is produced by
 //     permuting WHICH 16-byte piece of global memory each lane fetches; fragment
@@ -26,7 +27,7 @@
 
 namespace sbamd {
 
-constexpr int DMA_BM = 256, DMA_BN = 256, DMA_NT = 512;
+constexpr int DMA_BM = 256, DMA_BN = 256, DMA_NT = 512;  // the big tile
 
 typedef __attribute__((address_space(1))) const void* dma_gptr_t;
 typedef __attribute__((address_space(3))) void* dma_lptr_t;
@@ -40,18 +41,18 @@ typedef __attribute__((address_space(3))) void* dma_lptr_t;
 // has seen its own pieces of tile t + 1 land (the first fragments of tile t + 1 are
 // fetched behind the remaining matrix instructions).
 constexpr int RING_BK = 32, RING_STAGES = 5, RING_AHEAD = 4;
-constexpr int RING_OPERAND_BYTES = 256 * RING_BK * 2;       // 16 KiB
-constexpr int RING_STAGE_BYTES = 2 * RING_OPERAND_BYTES;    // 32 KiB
-constexpr int RING_LDS_BYTES = RING_STAGES * RING_STAGE_BYTES;
+constexpr int ring_operand_bytes(int rows) { return rows * RING_BK * 2; }  // 256 rows: 16 KiB
+constexpr int ring_lds_bytes(int bm, int bn) { return RING_STAGES * (ring_operand_bytes(bm) + ring_operand_bytes(bn)); }
+constexpr int RING_LDS_BYTES = ring_lds_bytes(DMA_BM, DMA_BN);
 
-// Images per stage and operand (16 KiB):
-//   K-contiguous:   [256 mn][32 k], 64-byte rows of four 16-byte pieces; piece c of row
+// Images per stage and operand (ROWS = 256 or 128 indices along M / N; 16 or 8 KiB):
+//   K-contiguous:   [ROWS mn][32 k], 64-byte rows of four 16-byte pieces; piece c of row
 //                   r sits at position c ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128
 //                   lane group cover the 16 slots of the bank row.
-//   M/N-contiguous: [32 k][256 mn], 512-byte rows of 32 pieces; piece c of row k sits at
-//                   position c ^ ((k & 3) << 2): the four k rows that one
-//                   ds_read_b64_tr_b16 lane group touches land on four different
-//                   64-byte bank segments.
+//   M/N-contiguous: [32 k][ROWS mn], rows of ROWS / 8 pieces (512 or 256 bytes, whole
+//                   turns of the 64 banks); piece c of row k sits at position
+//                   c ^ ((k & 3) << 2): the four k rows that one ds_read_b64_tr_b16 lane
+//                   group touches land on four different 64-byte bank segments.
 // ds_read_b64_tr_b16 as inline assembly: behind the builtin the compiler drains every
 // outstanding LDS-writing load (s_waitcnt vmcnt(0)) before each transposing read,
 // which would serialise the ring.  The caller waits (lgkmcnt) before using the result.
@@ -71,14 +72,18 @@ __device__ inline int ring_swizzle_mn(int krow) {
   return (krow & 3) << 2;
 }
 
-template <bool KMAJOR, int SHAPE = 32>
+template <bool KMAJOR, int ROWS = 256, int NT = DMA_NT, int SHAPE = 32>
 struct RingOperand {
+  static_assert(ROWS * 4 == 2 * NT, "two 16-byte pieces per thread and operand tile");
+  static_assert(ROWS % 128 == 0, "the M/N-contiguous swizzle moves a piece by up to 12 positions inside its row");
+  static constexpr int PER_KROW = ROWS / 8;  // pieces per k row of the M/N-contiguous image
+  static constexpr int BYTES = ring_operand_bytes(ROWS);
   const uint16_t* src[2];
 
   __device__ inline void init(const uint16_t* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim, int tid) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int L = i * DMA_NT + tid;  // 1024 pieces per operand tile
+      const int L = i * NT + tid;  // ROWS * 4 pieces per operand tile
       if (KMAJOR) {
         const int row = L >> 2;
         const int c = (L & 3) ^ ring_swizzle_k<SHAPE>(row);
@@ -86,8 +91,8 @@ struct RingOperand {
         mn = mn < mn_lim ? mn : mn_lim - 1;
         src[i] = x + mn * ld + c * 8;
       } else {
-        const int krow = L >> 5;
-        const int c = (L & 31) ^ ring_swizzle_mn<SHAPE>(krow);
+        const int krow = L / PER_KROW;
+        const int c = (L % PER_KROW) ^ ring_swizzle_mn<SHAPE>(krow);
         int64_t mn = mn0 + c * 8;
         mn = mn < mn_lim ? mn : mn_lim - 8;
         src[i] = x + mn + int64_t(krow) * ld;
@@ -98,7 +103,7 @@ struct RingOperand {
   // Piece i of this thread for the tile the pointers address.
   template <int I>
   __device__ inline void issue_piece(SBAMD_LDS unsigned char* lds, int wave) {
-    SBAMD_LDS unsigned char* dst = lds + (I * DMA_NT + wave * 64) * 16;
+    SBAMD_LDS unsigned char* dst = lds + (I * NT + wave * 64) * 16;
     __builtin_amdgcn_global_load_lds((dma_gptr_t)src[I], (dma_lptr_t)dst, 16, 0, 0);
   }
   __device__ inline void advance(int64_t ld) {
@@ -111,7 +116,7 @@ struct RingOperand {
   // pointers stand after the main loop): through registers, zeros past the end of K.
   template <int I>
   __device__ inline u16x8 load_tail(int k_rem, int tid) const {
-    const int L = I * DMA_NT + tid;
+    const int L = I * NT + tid;
     u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (KMAJOR) {
       const int row = L >> 2;
@@ -124,13 +129,13 @@ struct RingOperand {
           if (kl + e < k_rem) v[e] = src[I][e];
       }
     } else {
-      if ((L >> 5) < k_rem) v = *reinterpret_cast<const u16x8*>(src[I]);
+      if (L / PER_KROW < k_rem) v = *reinterpret_cast<const u16x8*>(src[I]);
     }
     return v;
   }
   template <int I>
   __device__ static inline void store_tail(SBAMD_LDS unsigned char* lds, int tid, u16x8 v) {
-    *reinterpret_cast<SBAMD_LDS u16x8*>(lds + (I * DMA_NT + tid) * 16) = v;
+    *reinterpret_cast<SBAMD_LDS u16x8*>(lds + (I * NT + tid) * 16) = v;
   }
 
   // Fragment of k-step S (16 k) for the 32 rows starting at tile-relative mn0.
@@ -145,9 +150,10 @@ struct RingOperand {
       const int g = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
       const int col = mn0 + 16 * g + 4 * p;
       const int c = (col >> 3) ^ (q << 2);
-      const uint32_t addr = uint32_t(uintptr_t(lds)) + uint32_t((8 * h + q) * 512 + c * 16 + (col & 7) * 2);
-      const s16x4 lo = ds_read_tr16<S * 16 * 512>(addr);
-      const s16x4 hi = ds_read_tr16<S * 16 * 512 + 4 * 512>(addr);
+      constexpr int ROW_BYTES = ROWS * 2;
+      const uint32_t addr = uint32_t(uintptr_t(lds)) + uint32_t((8 * h + q) * ROW_BYTES + c * 16 + (col & 7) * 2);
+      const s16x4 lo = ds_read_tr16<S * 16 * ROW_BYTES>(addr);
+      const s16x4 hi = ds_read_tr16<S * 16 * ROW_BYTES + 4 * ROW_BYTES>(addr);
       u16x8 out;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -162,13 +168,17 @@ struct RingOperand {
 
 // ABLATE is a timing-only diagnostic (bit 1: no loads inside the K loop, bit 2: no matrix
 // instructions, bit 4: no fragment reads); the library instantiates 0.
-template <typename Tag, typename TOut, bool TA, bool TB, int ABLATE = 0>
-__global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmArgs16<TOut> g) {
-  constexpr int WM = 2, WN = 4;
-  constexpr int WTM = DMA_BM / WM, WTN = DMA_BN / WN;
+// BM x BN tile on WM x WN wavefronts: 256 x 256 on 2 x 4 (wave tile 128 x 64) or 128 x 128 on 2 x 2 (64 x 64).
+template <typename Tag, typename TOut, bool TA, bool TB, int ABLATE = 0, int BM = DMA_BM, int BN = DMA_BN, int WM = 2, int WN = 4>
+__global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const GemmArgs16<TOut> g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 32, NI = WTN / 32;
-  using OpA = RingOperand<TA>;
-  using OpB = RingOperand<!TB>;
+  constexpr int NM = MI * NI;  // matrix instructions per half step
+  using OpA = RingOperand<TA, BM, NT>;
+  using OpB = RingOperand<!TB, BN, NT>;
+  constexpr int RING_OPERAND_BYTES = OpA::BYTES;  // offset of the B image inside a stage
+  constexpr int RING_STAGE_BYTES = OpA::BYTES + OpB::BYTES;
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
   SBAMD_LDS unsigned char* smem = (SBAMD_LDS unsigned char*)smem_raw;
@@ -186,7 +196,7 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
   const int z = logical / ntiles;
   int tm, tn;
   tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
-  const int64_t m0 = int64_t(tm) * DMA_BM, n0 = int64_t(tn) * DMA_BN;
+  const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
   const uint16_t* a = g.a + int64_t(z) * g.stride_a;
   const uint16_t* b = g.b + int64_t(z) * g.stride_b;
   TOut* c = g.c + int64_t(z) * g.stride_c;
@@ -250,20 +260,23 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
       if constexpr (!(ABLATE & 2)) acc[I][J] = Mfma16<Tag>::mma(cb[J], ca[I], acc[I][J]);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (READS && N < MI + NI && !(ABLATE & 4)) read_unit(std::integral_constant<int, N>{}, s_next_tag, st_next, na, nb);
-      if constexpr (LOADS && N == 2 && !(ABLATE & 1)) oa.template issue_piece<PIECE>(fill, wave);
-      if constexpr (LOADS && N == 5 && !(ABLATE & 1)) ob.template issue_piece<PIECE>(fill + RING_OPERAND_BYTES, wave);
+      if constexpr (LOADS && N == NM / 4 && !(ABLATE & 1)) oa.template issue_piece<PIECE>(fill, wave);
+      if constexpr (LOADS && N == NM / 2 + NM / 4 - (NM > 4 ? 1 : 0) && !(ABLATE & 1)) ob.template issue_piece<PIECE>(fill + RING_OPERAND_BYTES, wave);
       __builtin_amdgcn_sched_barrier(0);
     };
     slot(std::integral_constant<int, 0>{});
     slot(std::integral_constant<int, 1>{});
     slot(std::integral_constant<int, 2>{});
     slot(std::integral_constant<int, 3>{});
-    slot(std::integral_constant<int, 4>{});
-    slot(std::integral_constant<int, 5>{});
-    slot(std::integral_constant<int, 6>{});
-    slot(std::integral_constant<int, 7>{});
+    if constexpr (NM > 4) {
+      slot(std::integral_constant<int, 4>{});
+      slot(std::integral_constant<int, 5>{});
+      slot(std::integral_constant<int, 6>{});
+      slot(std::integral_constant<int, 7>{});
+    }
   };
-  static_assert(MI * NI == 8 && MI + NI <= 8, "the slot list above is written for the 128 x 64 wave tile");
+  // load pieces behind matrix instructions 2 and 5 of eight, 1 and 3 of four
+  static_assert((NM == 8 || NM == 4) && MI + NI <= NM, "the slot list above is written for wave tiles of 128 x 64 and 64 x 64");
 
   // first fragments of tile 0
   {
@@ -272,8 +285,10 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
     all(std::integral_constant<int, 1>{});
     all(std::integral_constant<int, 2>{});
     all(std::integral_constant<int, 3>{});
-    all(std::integral_constant<int, 4>{});
-    all(std::integral_constant<int, 5>{});
+    if constexpr (MI + NI > 4) {
+      all(std::integral_constant<int, 4>{});
+      all(std::integral_constant<int, 5>{});
+    }
   }
 
   // One K step.  LOADS: tile t + RING_AHEAD exists and is issued here; NEXT: tile
@@ -341,8 +356,10 @@ __global__ void __launch_bounds__(DMA_NT, 2) gemm_mfma16_ring_kernel(const GemmA
       all(std::integral_constant<int, 1>{});
       all(std::integral_constant<int, 2>{});
       all(std::integral_constant<int, 3>{});
-      all(std::integral_constant<int, 4>{});
-      all(std::integral_constant<int, 5>{});
+      if constexpr (MI + NI > 4) {
+        all(std::integral_constant<int, 4>{});
+        all(std::integral_constant<int, 5>{});
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposing reads are not tracked by the compiler
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
