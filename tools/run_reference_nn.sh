@@ -2,7 +2,7 @@
 # The reference's AlexNet / VGG / ResNet GEMM shape suites (benchmark/config_csv/reference_nn/, the rows of the
 # reference's benchmark/config_csv/blas3/gemm/gemm_{inference,training}_*.csv) through bench_blas3 for float and
 # bf16, and every unique shape through the family tuner (float) for the planner-vs-best-candidate ratios.
-# usage: tools/run_reference_nn.sh    -> gpurun_out/reference_nn/
+# usage: [SKIP_TUNER=1] tools/run_reference_nn.sh    -> gpurun_out/reference_nn/
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/reference_nn
@@ -16,6 +16,7 @@ for f in benchmark/config_csv/reference_nn/*.csv; do
   done
   echo "suite $tag done"
 done
+[ -n "${SKIP_TUNER:-}" ] && exit 0
 rm -f $out/tune_f32.csv
 cat benchmark/config_csv/reference_nn/*.csv | grep -v "^#" | sort -u | while IFS=, read ta tb m k n al be; do
   timeout -k 10 60 benchmark/tune_gemm $m $k $n 1 5 --trans=nn --dtype=float --csv=$out/tune_f32.csv >> $out/tune_f32.log 2>&1 || { echo "tune failed $m $k $n"; exit 1; }
