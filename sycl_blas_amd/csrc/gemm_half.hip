@@ -47,7 +47,7 @@ hipError_t launch16_dma_one(const GemmArgs16<TOut>& g, hipStream_t stream) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   if (e != hipSuccess) return e;
-  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * g.batch;
+  const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * (g.split_k > 1 ? g.split_k : g.batch);
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WM * WN * 64), lds, stream, g);
   return hipGetLastError();
@@ -76,7 +76,7 @@ hipError_t launch16_dma(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream
 //   64 x 64: 0.0079 us alone, 0.0043 per workgroup from four per unit on.
 // 3072^3 (144 big tiles, 56 % of the units) runs 65 us on the big tile against 81 on 128 x 128; 2304^3 40 us on
 // 128 x 128 against 49.
-inline int pick_family16(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, bool ring_ok) {
+inline int pick_family16(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, bool ring_ok, double* t_best = nullptr) {
   auto tiles = [&](int64_t b) { return double(ceil_div(m, b) * ceil_div(n, b) * batch); };
   const double kk = double(k);
   const double q256 = tiles(256) / cus, q128 = std::ceil(tiles(128) / cus), q64 = std::ceil(tiles(64) / cus);
@@ -87,8 +87,34 @@ inline int pick_family16(int64_t m, int64_t n, int64_t k, int64_t batch, int cus
                           : std::floor(q128 / 2.0) * 0.0193 + (std::fmod(q128, 2.0) != 0.0 ? 0.0141 : 0.0));
   const double per64 = q64 <= 1.0 ? 0.0079 : q64 <= 2.0 ? 0.0105 : q64 <= 3.0 ? 0.0147 : 0.0043 * q64;
   const double t_small = 5.0 + kk * per64;
+  if (t_best) *t_best = std::min(ring_ok ? t_huge : t_large, std::min(t_large, t_small));
   if (ring_ok && t_huge <= t_large && t_huge <= t_small) return SBAMD_KERNEL_HUGE;
   return t_large <= t_small ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
+}
+
+// How many K slabs on the 128 x 128 ring kernel (1 = no cut), from the same kind of estimate (tools/sweep16_split.py:
+// within 10 % of the measured time over depths 8 .. 512 on thin shapes): two launches (8 us); a slab's K range at
+// 0.0062 us per unit of K while every workgroup has a compute unit to itself, 0.0088 times the workgroups per unit
+// beyond that; never faster than the operands stream (4.7 TB/s with one workgroup per unit, 3.5 with more, and
+// no more than about 23 GB/s per workgroup);
+// the reduction walks the slabs one after the other: 0.2 us per slab plus the slab's bytes written and read back.
+// A cut has to beat the best single launch by 10 %.
+inline int64_t pick_depth16(int64_t m, int64_t n, int64_t k, int cus, double t_single) {
+  const double tiles = double(ceil_div(m, 128) * ceil_div(n, 128));
+  const double bytes_ab = 2.0 * (double(m) * double(k) + double(k) * double(n));
+  const double per_slab = 0.2 + double(m) * double(n) * 8.0 / 5e6;
+  int64_t best = 1;
+  double best_t = 0.9 * t_single;
+  const int64_t d_max = std::min<int64_t>(512, k / 128);
+  for (int64_t d = 2; d <= d_max; ++d) {
+    const double wgs = tiles * double(d);
+    const double q = std::ceil(wgs / cus);
+    const double k_part = double(k) / double(d) * (q <= 1.0 ? 0.0062 : 0.0088 * q);
+    const double stream = bytes_ab / std::min(q <= 1.0 ? 4.7e6 : 3.5e6, wgs * 23e3);
+    const double t = 8.0 + std::max(k_part, stream) + double(d) * per_slab;
+    if (t < best_t) best_t = t, best = d;
+  }
+  return best;
 }
 
 inline bool vec16_ok(const uint16_t* p, int64_t ld, int64_t stride, int64_t batch) {
@@ -198,22 +224,30 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
   // vector straddling the matrix edge.
   const bool dma_ok = g.vec_a && g.vec_b && p.k >= RING_BK && (p.ta || p.m % 8 == 0) && (!p.tb || p.n % 8 == 0);
   int family = h->kernel_override;
+  double t_single = 0.0;  // estimated microseconds of the best single launch (automatic choice only)
   if (family == SBAMD_KERNEL_HUGE && !dma_ok) family = SBAMD_KERNEL_AUTO;
   if (family != SBAMD_KERNEL_LARGE && family != SBAMD_KERNEL_SMALL && family != SBAMD_KERNEL_HUGE) {
-    family = pick_family16(p.m, p.n, p.k, p.batch, cus, dma_ok);
+    family = pick_family16(p.m, p.n, p.k, p.batch, cus, dma_ok, &t_single);
   }
-  // Few 64x64 tiles and a long K (thin transformer shapes: 48 x 4096 x 4096, 224 x 1024 x 32768):
-  // cut K over extra workgroups of the 64x64 kernel, fp32 partial sums in the handle's
-  // cube, one reduction that also applies beta*C and rounds to the output type.
+  // Few tiles and a long K (thin transformer shapes: 48 x 4096 x 4096, 224 x 1024 x 32768; weight-gradient
+  // shapes: 128 x 576 x 401408): cut K over extra workgroups, fp32 partial sums in the handle's cube, one
+  // reduction that also applies beta*C and rounds to the output type.  The slabs run on the 128 x 128 ring
+  // kernel where it can take the operands (128 x 576 x 401408: 318 -> 160 us, the operands then stream at
+  // 3.6 TB/s), else on the register-staged 64 x 64 tile.  Pinned: the low 16 bits of the parameter give the
+  // depth, bits 16-23 == 1 keep the register-staged tile.
   if (h->kernel_override == SBAMD_KERNEL_AUTO || h->kernel_override == SBAMD_KERNEL_SPLITK) {
+    const bool pinned = h->kernel_override == SBAMD_KERNEL_SPLITK;
     const int64_t tiles64 = ceil_div(p.m, 64) * ceil_div(p.n, 64);
-    int64_t depth = h->kernel_override == SBAMD_KERNEL_SPLITK && (h->kernel_param & 0xffff) > 0
-                        ? (h->kernel_param & 0xffff)
-                        : std::min<int64_t>(ceil_div(4 * int64_t(cus), tiles64), p.k / 128);
-    // ... unless the 128 x 128 ring kernel has tiles for half of the units: it then finishes first without
-    // the second launch (512 x 4096 x 4096: 34 us against 46 cut in two)
-    const bool ring_fills = dma_ok && ceil_div(p.m, 128) * ceil_div(p.n, 128) * 2 >= cus;
-    if (p.batch == 1 && (h->kernel_override == SBAMD_KERNEL_SPLITK || (!ring_fills && ((tiles64 * 2 <= cus && p.k >= 1024) || (tiles64 <= 2 * cus && p.k >= 2048)))) && depth > 1) {
+    const bool ring_slabs = dma_ok && !(pinned && ((h->kernel_param >> 16) & 0xff) == 1);
+    int64_t depth = 1;
+    if (pinned && (h->kernel_param & 0xffff) > 0) {
+      depth = h->kernel_param & 0xffff;
+    } else if (p.batch == 1 && ring_slabs) {
+      depth = pick_depth16(p.m, p.n, p.k, cus, pinned ? 1e30 : t_single);
+    } else if (p.batch == 1 && (pinned || (tiles64 * 2 <= cus && p.k >= 1024) || (tiles64 <= 2 * cus && p.k >= 2048))) {
+      depth = std::min<int64_t>(ceil_div(4 * int64_t(cus), tiles64), p.k / 128);
+    }
+    if (p.batch == 1 && depth > 1) {
       const int64_t k_chunk = 32 * ceil_div(p.k, 32 * depth);
       depth = ceil_div(p.k, k_chunk);
       if (depth > 1) {
@@ -230,7 +264,8 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
         gp.vec_a = g.vec_a, gp.vec_b = g.vec_b;
         gp.alpha = alpha, gp.beta = 0.0f, gp.beta_zero = 1;
         gp.split_k = int32_t(depth), gp.k_chunk = k_chunk, gp.slice_stride = slice;
-        e = launch16<Tag, float, 64, 64, 32, 2, 2>(gp, p.ta, p.tb, h->stream);
+        e = ring_slabs ? launch16_dma<Tag, float, 128, 128, 2, 2>(gp, p.ta, p.tb, h->stream)
+                       : launch16<Tag, float, 64, 64, 32, 2, 2>(gp, p.ta, p.tb, h->stream);
         if (e != hipSuccess) return e;
         const int64_t grid = ceil_div(slice, 256);
         hipLaunchKernelGGL((splitk_reduce16_kernel<TOut>), dim3((unsigned)grid), dim3(256), 0, h->stream,

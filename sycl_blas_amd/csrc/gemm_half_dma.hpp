@@ -197,9 +197,23 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const 
   int tm, tn;
   tile_coords(logical - z * ntiles, g.tiles_m, g.tiles_n, tm, tn);
   const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
-  const uint16_t* a = g.a + int64_t(z) * g.stride_a;
-  const uint16_t* b = g.b + int64_t(z) * g.stride_b;
-  TOut* c = g.c + int64_t(z) * g.stride_c;
+  const uint16_t* a = g.a;
+  const uint16_t* b = g.b;
+  TOut* c = g.c;
+  int64_t k_len = g.k;
+  if (g.split_k > 1) {
+    // K slab z (k_chunk is a multiple of the K step, so only the last slab can end in a tail): alpha * (its
+    // partial sum) goes to slice z of the cube
+    const int64_t k_begin = int64_t(z) * g.k_chunk;
+    k_len = g.k - k_begin < g.k_chunk ? g.k - k_begin : g.k_chunk;
+    a += TA ? k_begin : k_begin * g.lda;
+    b += TB ? k_begin * g.ldb : k_begin;
+    c += int64_t(z) * g.slice_stride;
+  } else {
+    a += int64_t(z) * g.stride_a;
+    b += int64_t(z) * g.stride_b;
+    c += int64_t(z) * g.stride_c;
+  }
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -213,7 +227,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const 
   OpB ob;
   oa.init(a, g.lda, m0, g.m, tid);
   ob.init(b, g.ldb, n0, g.n, tid);
-  const int nk = int(g.k / RING_BK);
+  const int nk = int(k_len / RING_BK);
 
   auto stage_ptr = [&](int t) { return smem + (t % RING_STAGES) * RING_STAGE_BYTES; };
 
@@ -340,7 +354,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const 
 
   // K tail (k % 32 valid k): one more tile, zero-padded, staged through registers into stage 0 once every
   // wavefront has finished the last ring step; the zeros add nothing to the sums.
-  const int k_rem = int(g.k - int64_t(nk) * RING_BK);
+  const int k_rem = int(k_len - int64_t(nk) * RING_BK);
   if (k_rem > 0) {
     __syncthreads();
     const u16x8 a0 = oa.template load_tail<0>(k_rem, tid), a1 = oa.template load_tail<1>(k_rem, tid);
