@@ -107,7 +107,13 @@ const char* sbamd_last_error(sbamd_handle_t h);
  * the cube (same result as the cube route with two slabs; needs K to split into two equal halves whose
  * start stays 16-byte aligned, else the cube route runs).
  * SBAMD_KERNEL_SMALL: bit 0 = keep the register-staged kernel where the direct-to-LDS one would run
- * (fp32, A 'n', B 't'; same bits either way -- a switch for A/B timing). */
+ * (fp32, A 'n', B 't'; same bits either way -- a switch for A/B timing).
+ * 16-bit entry points: SBAMD_KERNEL_HUGE / SBAMD_KERNEL_LARGE are the 256x256 / 128x128 tiles of the
+ * direct-to-LDS kernel where the operands allow it (16-byte aligned, leading dimensions multiples of 8, K >= 32,
+ * M / N a multiple of 8 along a contiguous operand), else HUGE falls back to the automatic choice and LARGE to
+ * the register-staged 128x128 kernel; SBAMD_KERNEL_LARGE bit 0 = keep the register-staged kernel anyway;
+ * split-K bits 16-23 == 1 = K slabs on the register-staged 64x64 tile instead of the direct-to-LDS 128x128 one.
+ * Every 16-bit kernel produces the same bits for the same K cut. */
 int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param);
 
 /* Which family the last GEMM call on this handle launched (SBAMD_KERNEL_*),
