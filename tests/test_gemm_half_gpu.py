@@ -223,3 +223,46 @@ def test_alpha_zero_and_beta_zero_on_half_output(sb_handle):
     assert (out.view(np.float16) == 16).all()
     with pytest.raises(ValueError, match="invalid _TransB"):
         sb._gemm(h, "n", "q", m, n, 16, 1.0, a_g, m, a_g, m, 0.0, c_g, m)
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_every_kernel_gives_the_same_bits(sb_handle, pair):
+    """One problem through every 16-bit kernel that can take it: the register-staged tiles, both tiles of the
+    direct-to-LDS kernel, and -- for one K cut -- slabs on either kernel.  All of them feed the same matrix
+    instruction the same 16 k at a time in the same order, so the outputs have to be identical, K tail included."""
+    h = sb_handle
+    storage, out_name = pair
+    for (m, n, k), ta, tb in itertools.product([(264, 392, 616), (136, 520, 1000)], "nt", "nt"):
+        rng = seeded("same-bits", pair, m, n, k, ta, tb)
+        lda, ldb = (k if ta != "n" else m), (n if tb != "n" else k)
+        a_bits, _ = make_inputs(rng, m * k, storage)
+        b_bits, _ = make_inputs(rng, k * n, storage)
+        c0 = rng.uniform(-2.0, 5.0, m * n).astype(np.float16 if out_name == "float16" else np.float32)
+        c_dev = c0.view(np.uint16).copy() if out_name == "float16" else c0
+        a_g, b_g, c_g = (helper.allocate(h, storage, a_bits.size), helper.allocate(h, storage, b_bits.size),
+                         helper.allocate(h, out_name, c_dev.size))
+        helper.copy_to_device(h, a_bits, a_g)
+        helper.copy_to_device(h, b_bits, b_g)
+
+        def run(family, param):
+            h.set_kernel(family, param)
+            helper.copy_to_device(h, c_dev, c_g)
+            sb._gemm(h, ta, tb, m, n, k, 1.5, a_g, lda, b_g, ldb, 0.5, c_g, m)
+            out = np.empty_like(c_dev)
+            h.wait(helper.copy_to_host(h, c_g, out))
+            return out, h.last_kernel()
+
+        try:
+            base, ran = run(_lib.KERNEL_SMALL, 0)
+            assert ran == _lib.KERNEL_SMALL
+            for family, param in [(_lib.KERNEL_LARGE, 0), (_lib.KERNEL_LARGE, 1), (_lib.KERNEL_HUGE, 0)]:
+                got, ran = run(family, param)
+                assert ran == family and np.array_equal(got, base), (pair, m, n, k, ta, tb, family, param)
+            ring, ran = run(_lib.KERNEL_SPLITK, 3)
+            assert ran == _lib.KERNEL_SPLITK and h.last_splitk()[0] == 3
+            staged, _ = run(_lib.KERNEL_SPLITK, 3 | (1 << 16))
+            assert h.last_splitk()[0] == 3 and np.array_equal(ring, staged), (pair, m, n, k, ta, tb, "K cut")
+        finally:
+            h.set_kernel(_lib.KERNEL_AUTO)
+            for buf in (a_g, b_g, c_g):
+                helper.deallocate(buf)
