@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--bands", type=int, default=0, help="column bands of the overlapped gather (0 = choose)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--one-rank-rccl", action="store_true",
+                    help="one process, one GPU, but through the N>1 code path with a one-rank RCCL group: checks that RCCL "
+                         "takes the in-place band gathers, streams and events as the multi-GPU run issues them (not a measurement)")
     ap.add_argument("--rehearse", action="store_true",
                     help="rank logic check on a box with fewer GPUs than ranks: every rank uses GPU 0 and the barrier / "
                          "max-over-ranks go through gloo; the number it prints is not a multi-GPU measurement")
@@ -296,12 +299,12 @@ class StagedGather:
         return None
 
 
-def timed_steps(torch, dist, world, step, steps, handle=None, events=None):
+def timed_steps(torch, dist, dist_on, step, steps, handle=None, events=None):
     """EXACTLY `steps` steps between a barrier + device synchronisation on both sides; seconds on this rank.
     With `handle` and `events`, a HIP event is recorded on the handle's stream right before the first and right
     after the last step (device time of the same region)."""
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     if events is not None:
@@ -312,14 +315,14 @@ def timed_steps(torch, dist, world, step, steps, handle=None, events=None):
     if events is not None:
         events.append(handle.record_event())
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
 
-def max_over_ranks(torch, dist, world, seconds, on_cpu):
-    if world == 1:
+def max_over_ranks(torch, dist, dist_on, seconds, on_cpu):
+    if not dist_on:
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -342,7 +345,13 @@ def main():
     if args.rehearse:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    dist_on = world > 1 or args.one_rank_rccl
+    if args.one_rank_rccl:
+        if world != 1:
+            raise SystemExit("--one-rank-rccl is a single-process run")
+        for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29561"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(key, val)
+    if dist_on:
         if args.rehearse:
             dist.init_process_group("gloo")
         else:
@@ -359,7 +368,7 @@ def main():
     ta, tb = args.trans[0], args.trans[1]
     size = args.size
     pr, pc = grid_for(world)
-    strong = world > 1 and args.mode == "strong"
+    strong = dist_on and args.mode == "strong"
     gather = strong and not args.no_gather
     comm = StagedGather(dist, torch) if args.rehearse else dist
     extras = {}
@@ -410,8 +419,8 @@ def main():
     for _ in range(args.warmup):
         step()
     region = []
-    wall = timed_steps(torch, dist, world, step, args.steps, handle, region)
-    wall = max_over_ranks(torch, dist, world, wall, args.rehearse)
+    wall = timed_steps(torch, dist, dist_on, step, args.steps, handle, region)
+    wall = max_over_ranks(torch, dist, dist_on, wall, args.rehearse)
     flops_job = 2.0 * gm * gn * gk
     value = flops_job * args.steps / wall / 1e12
 
@@ -437,8 +446,8 @@ def main():
                         wk.wait()
             for _ in range(2):
                 gather_only()
-            t_g = timed_steps(torch, dist, world, gather_only, max(3, args.steps // 2)) / max(3, args.steps // 2)
-            extras["strong"]["gather_only_ms_per_step"] = round(max_over_ranks(torch, dist, world, t_g, args.rehearse) * 1e3, 4)
+            t_g = timed_steps(torch, dist, dist_on, gather_only, max(3, args.steps // 2)) / max(3, args.steps // 2)
+            extras["strong"]["gather_only_ms_per_step"] = round(max_over_ranks(torch, dist, dist_on, t_g, args.rehearse) * 1e3, 4)
             # every rank must hold the same C, and a foreign part must equal this rank's own recomputation
             # of it (same kernel, same shape: bit for bit)
             step()
@@ -462,8 +471,8 @@ def main():
         wops = Operands(torch, sb, handle, args.dtype, ta, tb, size, size, size, 999 + rank)
         for _ in range(3):
             wops.run(sb, handle)
-        t_w = timed_steps(torch, dist, world, lambda: wops.run(sb, handle), max(3, args.steps // 2)) / max(3, args.steps // 2)
-        t_w = max_over_ranks(torch, dist, world, t_w, args.rehearse)
+        t_w = timed_steps(torch, dist, dist_on, lambda: wops.run(sb, handle), max(3, args.steps // 2)) / max(3, args.steps // 2)
+        t_w = max_over_ranks(torch, dist, dist_on, t_w, args.rehearse)
         extras["weak_no_exchange"] = {"job": f"{pr * size}x{pc * size}x{size}", "tflops": round(2.0 * size ** 3 * world / t_w / 1e12, 2),
                                       "ms_per_step": round(t_w * 1e3, 4)}
         del wops
@@ -508,20 +517,22 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": load_traffic(args.dtype, args.trans, size) if world == 1 else None,
+                "traffic": load_traffic(args.dtype, args.trans, size) if not dist_on else None,
                 "kernel": f"gemm_mfma_kernel<{'float' if args.dtype == 'f32' else 'double'}> (tile family "
                           f"{handle.last_kernel()}), {kernel_ms:.4f} ms per step of this rank's multiplications",
             },
         }
         if args.rehearse:
             out["config"]["rehearsal"] = "all ranks on GPU 0, collectives staged through the host: NOT a multi-GPU measurement"
+        if args.one_rank_rccl:
+            out["config"]["rehearsal"] = "the N>1 code path on a one-rank RCCL group: NOT a multi-GPU measurement"
         if extras:
             out["extras"] = extras
 
-        if not args.no_extras and world == 1:
+        if not args.no_extras and not dist_on:
             out["extras"] = side_measurements(torch, sb, handle, size)
 
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and not dist_on:
             try:
                 base, c_cpu, cols, c_1024 = cpu_baseline(args.dtype, ta, tb, size, 12345)
                 out["cpu_baseline"] = base
@@ -546,7 +557,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     handle.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
