@@ -275,13 +275,15 @@ def cpu_baseline(dtype, ta, tb, size, seed):
 
 def load_traffic(dtype, trans, size):
     """HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/*.json), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            table = json.load(f)
-        return table.get(f"{dtype}_{trans}_{size}")
-    except Exception:
-        return None
+    for path in (os.path.join(ROOT, "profiles", "r02", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")):
+        try:
+            with open(path) as f:
+                table = json.load(f)
+            if f"{dtype}_{trans}_{size}" in table:
+                return table[f"{dtype}_{trans}_{size}"]
+        except Exception:
+            pass
+    return None
 
 
 class StagedGather:
