@@ -113,6 +113,9 @@ const char* sbamd_last_error(sbamd_handle_t h);
  * M / N a multiple of 8 along a contiguous operand), else HUGE falls back to the automatic choice and LARGE to
  * the register-staged 128x128 kernel; SBAMD_KERNEL_LARGE bit 0 = keep the register-staged kernel anyway;
  * split-K bits 16-23 == 1 = K slabs on the register-staged 64x64 tile instead of the direct-to-LDS 128x128 one.
+ * SBAMD_KERNEL_AUTO bit 0 = always copy operands the direct-to-LDS kernel cannot take as they lie (odd leading
+ * dimension or offset, M / N not a multiple of 8) into padded aligned buffers, where the library would otherwise
+ * do so only for products big enough to pay for the copies.
  * Every 16-bit kernel produces the same bits for the same K cut. */
 int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param);
 

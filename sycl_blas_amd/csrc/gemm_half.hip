@@ -222,7 +222,53 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
   // The direct-to-LDS 256x256 kernel needs at least one whole K step, 16-byte vectors and no
   // vector straddling the matrix edge.
-  const bool dma_ok = g.vec_a && g.vec_b && p.k >= RING_BK && (p.ta || p.m % 8 == 0) && (!p.tb || p.n % 8 == 0);
+  bool dma_ok = g.vec_a && g.vec_b && p.k >= RING_BK && (p.ta || p.m % 8 == 0) && (!p.tb || p.n % 8 == 0);
+  // A big product whose operands that kernel cannot take as they lie (odd leading dimension or offset, M / N not a
+  // multiple of 8 along a contiguous operand): copy the offending operand(s) into the handle's second scratch area
+  // with columns padded to whole vectors, when the copies cost less than the register-staged kernels lose
+  // (bf16 4100^3: 264 -> about 215 us).
+  // (not for operands that already live in that scratch area: the repacked items of an interleaved batch)
+  auto in_aux = [&](const void* q) {
+    const unsigned char* lo = static_cast<const unsigned char*>(h->aux);
+    return lo && static_cast<const unsigned char*>(q) >= lo && static_cast<const unsigned char*>(q) < lo + h->aux_bytes;
+  };
+  if (!dma_ok && p.batch == 1 && p.k >= RING_BK && h->kernel_override == SBAMD_KERNEL_AUTO && !in_aux(p.a) && !in_aux(p.b) &&
+      !in_aux(p.c)) {
+    const bool fix_a = !g.vec_a || (!p.ta && p.m % 8 != 0), fix_b = !g.vec_b || (p.tb && p.n % 8 != 0);
+    const int64_t rows_a = p.ta ? p.k : p.m, cols_a = p.ta ? p.m : p.k, rows_b = p.tb ? p.n : p.k, cols_b = p.tb ? p.k : p.n;
+    const int64_t lda2 = ceil_div(rows_a, 8) * 8, ldb2 = ceil_div(rows_b, 8) * 8;
+    const double moved = (fix_a ? 4.0 * double(lda2) * double(cols_a) : 0.0) + (fix_b ? 4.0 * double(ldb2) * double(cols_b) : 0.0);
+    const double t_copy = 3.0 * (int(fix_a) + int(fix_b)) + moved / 3.5e6;
+    double t_ring = 0.0, t_staged = 0.0;
+    pick_family16(p.m, p.n, p.k, p.batch, cus, true, &t_ring);
+    pick_family16(p.m, p.n, p.k, p.batch, cus, false, &t_staged);
+    const bool forced = (h->kernel_param & 1) != 0;  // SBAMD_KERNEL_AUTO with bit 0 of the parameter: always copy (tests)
+    if (forced || t_ring + t_copy < 0.9 * t_staged) {
+      const size_t bytes_a = fix_a ? size_t(lda2) * size_t(cols_a) * 2 : 0, bytes_b = fix_b ? size_t(ldb2) * size_t(cols_b) * 2 : 0;
+      const size_t off_b = (bytes_a + 255) & ~size_t(255);
+      hipError_t e = ensure_aux(h, off_b + bytes_b);
+      if (e != hipSuccess) return e;
+      auto copy = [&](const uint16_t* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int64_t cols) {
+        const int64_t grid = ceil_div(ld_dst / 8 * cols, 256);
+        if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(copy_pad16_kernel, dim3((unsigned)grid), dim3(256), 0, h->stream, src, ld_src, dst, ld_dst, rows, cols);
+        return hipGetLastError();
+      };
+      if (fix_a) {
+        uint16_t* dst = static_cast<uint16_t*>(h->aux);
+        if ((e = copy(p.a, p.lda, dst, lda2, rows_a, cols_a)) != hipSuccess) return e;
+        g.a = dst, g.lda = lda2, g.vec_a = 1;
+        if (!p.ta) g.lim_a = lda2;
+      }
+      if (fix_b) {
+        uint16_t* dst = reinterpret_cast<uint16_t*>(static_cast<unsigned char*>(h->aux) + off_b);
+        if ((e = copy(p.b, p.ldb, dst, ldb2, rows_b, cols_b)) != hipSuccess) return e;
+        g.b = dst, g.ldb = ldb2, g.vec_b = 1;
+        if (p.tb) g.lim_b = ldb2;
+      }
+      dma_ok = true;
+    }
+  }
   int family = h->kernel_override;
   double t_single = 0.0;  // estimated microseconds of the best single launch (automatic choice only)
   if (family == SBAMD_KERNEL_HUGE && !dma_ok) family = SBAMD_KERNEL_AUTO;
@@ -262,6 +308,7 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
         gp.batch = 1;
         gp.tiles_m = gp.tiles_n = 0;
         gp.vec_a = g.vec_a, gp.vec_b = g.vec_b;
+        gp.lim_a = g.lim_a, gp.lim_b = g.lim_b;
         gp.alpha = alpha, gp.beta = 0.0f, gp.beta_zero = 1;
         gp.split_k = int32_t(depth), gp.k_chunk = k_chunk, gp.slice_stride = slice;
         e = ring_slabs ? launch16_dma<Tag, float, 128, 128, 2, 2>(gp, p.ta, p.tb, h->stream)

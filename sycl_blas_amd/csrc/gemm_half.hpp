@@ -77,7 +77,32 @@ struct GemmArgs16 {
   // and writes alpha * (its partial sum) to c + z*slice_stride; 1 = no cut.
   int32_t split_k;
   int64_t k_chunk, slice_stride;
+  // Direct-to-LDS kernel: how many indices along M (N) of A (B) may be loaded, when that is more than m (n) --
+  // an operand copied into a buffer whose columns are padded to whole 16-byte vectors.  0 = m (n).
+  int64_t lim_a = 0, lim_b = 0;
 };
+
+// Copy a column-major rows x cols matrix of 16-bit elements (leading dimension ld_src, any alignment) into a
+// 16-byte aligned buffer with leading dimension ld_dst (a multiple of 8, >= rows); rows .. ld_dst - 1 are zeros.
+__global__ void __launch_bounds__(256)
+    copy_pad16_kernel(const uint16_t* __restrict__ src, int64_t ld_src, uint16_t* __restrict__ dst, int64_t ld_dst,
+                      int64_t rows, int64_t cols) {
+  typedef u16x8 u16x8_any __attribute__((aligned(2)));
+  const int64_t per_col = ld_dst / 8;
+  const int64_t v = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (v >= per_col * cols) return;
+  const int64_t col = v / per_col, r0 = (v - col * per_col) * 8;
+  const uint16_t* s = src + col * ld_src + r0;
+  u16x8 out = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (r0 + 8 <= rows) {
+    out = *reinterpret_cast<const u16x8_any*>(s);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (r0 + e < rows) out[e] = s[e];
+  }
+  *reinterpret_cast<u16x8*>(dst + col * ld_dst + r0) = out;
+}
 
 // Global -> registers -> LDS for one operand tile (BMN x BK, 16-bit elements).
 // KMAJOR: k contiguous in global memory (A transposed / B not transposed).

@@ -225,8 +225,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const 
 
   OpA oa;
   OpB ob;
-  oa.init(a, g.lda, m0, g.m, tid);
-  ob.init(b, g.ldb, n0, g.n, tid);
+  oa.init(a, g.lda, m0, g.lim_a > 0 ? g.lim_a : g.m, tid);
+  ob.init(b, g.ldb, n0, g.lim_b > 0 ? g.lim_b : g.n, tid);
   const int nk = int(k_len / RING_BK);
 
   auto stage_ptr = [&](int t) { return smem + (t % RING_STAGES) * RING_STAGE_BYTES; };

@@ -266,3 +266,17 @@ def test_every_kernel_gives_the_same_bits(sb_handle, pair):
             h.set_kernel(_lib.KERNEL_AUTO)
             for buf in (a_g, b_g, c_g):
                 helper.deallocate(buf)
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_unaligned_operands_of_big_products(sb_handle, pair):
+    """Big products whose operands the direct-to-LDS kernel cannot take as they lie (odd leading dimensions, an odd
+    offset, M / N not a multiple of 8): the library copies them into padded, aligned buffers first (here forced, at
+    sizes the CPU check finishes quickly: bit 0 of the automatic choice's parameter).  Checked like every other case."""
+    h = sb_handle
+    for (m, n, k), ta, tb in [((1100, 1300, 1028), "n", "n"), ((1036, 1540, 999), "t", "n"), ((1101, 1203, 1024), "n", "t"),
+                              ((1500, 1100, 1032), "t", "t"), ((301, 203, 2048), "n", "t"), ((7, 5, 64), "n", "t")]:
+        run_case(h, pair, m, n, k, ta, tb, 1.5, 0.5, offset=3, family=_lib.KERNEL_AUTO, param=1)
+        if m >= 1000:  # enough 64 x 64 tiles for the 128 x 128 direct-to-LDS tile to be the cheaper choice
+            assert h.last_kernel() in (_lib.KERNEL_HUGE, _lib.KERNEL_LARGE)
+        run_case(h, pair, m, n, k, ta, tb, -1.0, 0.0, ldm=2, offset=0, family=_lib.KERNEL_AUTO, param=1)
