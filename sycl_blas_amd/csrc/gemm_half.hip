@@ -226,7 +226,7 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
   // A big product whose operands that kernel cannot take as they lie (odd leading dimension or offset, M / N not a
   // multiple of 8 along a contiguous operand): copy the offending operand(s) into the handle's second scratch area
   // with columns padded to whole vectors, when the copies cost less than the register-staged kernels lose
-  // (bf16 4100^3: 264 -> about 215 us).
+  // (bf16 8188^3: 1800 -> 995 us).
   // (not for operands that already live in that scratch area: the repacked items of an interleaved batch)
   auto in_aux = [&](const void* q) {
     const unsigned char* lo = static_cast<const unsigned char*>(h->aux);
@@ -242,6 +242,8 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
     double t_ring = 0.0, t_staged = 0.0;
     pick_family16(p.m, p.n, p.k, p.batch, cus, true, &t_ring);
     pick_family16(p.m, p.n, p.k, p.batch, cus, false, &t_staged);
+    // misaligned 16-byte loads cost the register-staged kernels about 1.7x (bf16 4092^3: 287 us against 163 at 4096^3)
+    if (!g.vec_a || !g.vec_b) t_staged *= 1.7;
     const bool forced = (h->kernel_param & 1) != 0;  // SBAMD_KERNEL_AUTO with bit 0 of the parameter: always copy (tests)
     if (forced || t_ring + t_copy < 0.9 * t_staged) {
       const size_t bytes_a = fix_a ? size_t(lda2) * size_t(cols_a) * 2 : 0, bytes_b = fix_b ? size_t(ldb2) * size_t(cols_b) * 2 : 0;

@@ -1,5 +1,5 @@
 """Time every 16-bit tile family (pinned) on a list of shapes through the raw C ABI: which family should the
-dispatcher take where?  Usage: python tools/sweep16.py [bf16|f16]"""
+dispatcher take where?  Usage: python tools/sweep16.py [bf16|f16] [MxNxK ...]"""
 import ctypes as C
 import os
 import sys
@@ -18,6 +18,7 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "bf16"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[name]
     out_dt = torch.float32 if name == "bf16" else dt
+    shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[2:]] or SHAPES
     lib = _lib.load()
     fn = lib.sbamd_bsgemm if name == "bf16" else lib.sbamd_hgemm
     side = torch.cuda.Stream()
@@ -25,7 +26,7 @@ def main():
     h = C.c_void_p()
     assert lib.sbamd_create(C.byref(h), 0, C.c_void_p(side.cuda_stream)) == 0
     fams = [("auto", _lib.KERNEL_AUTO), ("huge", _lib.KERNEL_HUGE), ("large", _lib.KERNEL_LARGE), ("small", _lib.KERNEL_SMALL)]
-    for (m, n, k) in SHAPES:
+    for (m, n, k) in shapes:
         a = (torch.rand(m * k, device="cuda") * 7 - 2).to(dt)
         b = (torch.rand(k * n, device="cuda") * 7 - 2).to(dt)
         c = torch.empty(m * n, device="cuda", dtype=out_dt)
