@@ -235,15 +235,22 @@ hipError_t launch_naive(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stre
 // or two to a compute unit).  K <= 64 on the 64x64 tile is staged in one shot.
 template <typename T>
 struct Tiles;
+// SMALL_OCC: register bound of the 64 x 64 tile in waves per SIMD.  With a bound of one (512 registers) hipcc keeps
+// the accumulators of the double kernel in accumulation registers and copies all 32 of them to vector registers and
+// back around the matrix instructions of every K step (64 moves for 16 matrix instructions); bounded to two waves
+// (256 registers, of which it needs 114) the moves are gone.  The float kernel had such moves only in its
+// ragged-edge and clamped loops; it takes the same bound.
 template <>
 struct Tiles<float> {
   static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 256, HUGE_OCC = 2, TINY_BK = 16, STREAM_OCC = 4;
   static constexpr int LARGE_WM = 4;  // 128 x 128 as eight waves of 32 x 64: 4-6 % faster than four of 64 x 64 at 2048^3..4096^3
+  static constexpr int SMALL_OCC = 2;
 };
 template <>
 struct Tiles<double> {
   static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 128, HUGE_OCC = 1, TINY_BK = 8, STREAM_OCC = 2;
   static constexpr int LARGE_WM = 2;  // four waves of 64 x 64 (eight waves gain nothing in fp64)
+  static constexpr int SMALL_OCC = 2;
 };
 
 // What to launch: a tile shape and how many K slabs (1 = a single kernel).
@@ -536,7 +543,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     if (!slabs_dma)
       e = plan.tile == TILE_256   ? launch_huge<T>(gp, p.ta, p.tb, h->stream)
           : plan.tile == TILE_128 ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, Tiles<T>::LARGE_WM, 2, 2>(gp, p.ta, p.tb, h->stream)
-                                  : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(gp, p.ta, p.tb, h->stream);
+                                  : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2, Tiles<T>::SMALL_OCC>(gp, p.ta, p.tb, h->stream);
     if (e != hipSuccess) return e;
     const int64_t grid = ceil_div(slice, 256);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)grid), dim3(256), 0, h->stream,
@@ -582,7 +589,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       // cannot hide (alternating runs: fp64 1024^3 57.7 -> 52.8 us, 768^3 43.0 -> 38.8; fp32 1-2 %; same chain, same bits).
       if (p.k >= 4 * Tiles<T>::ONESHOT_BK && ceil_div(p.m, 64) * ceil_div(p.n, 64) * p.batch <= 2 * int64_t(cus))
         return launch_tile<T, 64, 64, Tiles<T>::ONESHOT_BK, 2, 2, sizeof(T) == 4 ? 4 : 2>(g, p.ta, p.tb, h->stream);
-      return launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2>(g, p.ta, p.tb, h->stream);
+      return launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2, Tiles<T>::SMALL_OCC>(g, p.ta, p.tb, h->stream);
   }
 }
 
