@@ -194,9 +194,8 @@ hipError_t launch_halves(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
 template <typename T>
 hipError_t launch_huge(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream);
 
-template <typename T>
-hipError_t launch_interleaved(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream) {
-  constexpr int IR = 4, IC = 4;
+template <typename T, int IR, int IC>
+hipError_t launch_interleaved_tile(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream) {
   const int64_t total = ceil_div(g.m, IR) * ceil_div(g.n, IC) * g.batch;
   const int64_t grid = ceil_div(total, 256);
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -208,6 +207,20 @@ hipError_t launch_interleaved(const GemmArgs<T>& g, bool ta, bool tb, hipStream_
     else hipLaunchKernelGGL((gemm_interleaved_kernel<T, false, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
   }
   return hipGetLastError();
+}
+
+// Register block of C per lane: 4 x 4 (eight loads feed sixteen multiply-adds per k) or 8 x 8 (sixteen loads feed
+// sixty-four: the loop is bound by load issue, not by memory -- fp32 8^3 x 262144: 4.2 -> 5.7 TB/s, 16 x 16 x 64 x
+// 32768: 2.9 -> 4.9, 64^3 x 4096: 130 -> 75 us).  The big block needs items it tiles without much padding and a
+// batch that still fills the chip with a quarter of the lanes.
+inline bool interleaved_big_block(int64_t m, int64_t n, int64_t batch, int cus) {
+  const int64_t pad8 = ceil_div(m, 8) * 8 * (ceil_div(n, 8) * 8), pad4 = ceil_div(m, 4) * 4 * (ceil_div(n, 4) * 4);
+  return 10 * pad8 <= 13 * pad4 && ceil_div(m, 8) * ceil_div(n, 8) * batch >= int64_t(cus) * 512;
+}
+template <typename T>
+hipError_t launch_interleaved(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream, int cus = 256) {
+  if (interleaved_big_block(g.m, g.n, g.batch, cus)) return launch_interleaved_tile<T, 8, 8>(g, ta, tb, stream);
+  return launch_interleaved_tile<T, 4, 4>(g, ta, tb, stream);
 }
 
 template <typename T>
@@ -442,7 +455,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     const bool repack = p.m >= 32 && p.n >= 32 && flops >= 10.0 * moved * (4.0 / sizeof(T));
     if (!repack) {
       h->last_kernel = SBAMD_KERNEL_INTERLEAVED;
-      return launch_interleaved<T>(g, p.ta, p.tb, h->stream);
+      return launch_interleaved<T>(g, p.ta, p.tb, h->stream, h->compute_units > 0 ? h->compute_units : 256);
     }
     const int64_t a_rows = p.ta ? p.k : p.m, a_cols = p.ta ? p.m : p.k;
     const int64_t b_rows = p.tb ? p.n : p.k, b_cols = p.tb ? p.k : p.n;

@@ -121,9 +121,8 @@ inline bool vec16_ok(const uint16_t* p, int64_t ld, int64_t stride, int64_t batc
   return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 8 == 0) && (batch <= 1 || stride % 8 == 0);
 }
 
-template <typename Tag, typename TOut>
-hipError_t launch16_interleaved(const GemmArgs16<TOut>& g, bool ta, bool tb, hipStream_t stream) {
-  constexpr int IR = 4, IC = 4;
+template <typename Tag, typename TOut, int IR, int IC>
+hipError_t launch16_interleaved_tile(const GemmArgs16<TOut>& g, bool ta, bool tb, hipStream_t stream) {
   const int64_t total = ceil_div(g.m, IR) * ceil_div(g.n, IC) * g.batch;
   const int64_t grid = ceil_div(total, 256);
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -135,6 +134,13 @@ hipError_t launch16_interleaved(const GemmArgs16<TOut>& g, bool ta, bool tb, hip
     else hipLaunchKernelGGL((gemm_interleaved16_kernel<Tag, TOut, false, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
   }
   return hipGetLastError();
+}
+
+// 4 x 4 or 8 x 8 block of C per lane, chosen as for the fp32 / fp64 kernel (interleaved_big_block).
+template <typename Tag, typename TOut>
+hipError_t launch16_interleaved(const GemmArgs16<TOut>& g, bool ta, bool tb, hipStream_t stream, int cus = 256) {
+  if (interleaved_big_block(g.m, g.n, g.batch, cus)) return launch16_interleaved_tile<Tag, TOut, 8, 8>(g, ta, tb, stream);
+  return launch16_interleaved_tile<Tag, TOut, 4, 4>(g, ta, tb, stream);
 }
 
 template <typename Tag, typename TOut>
@@ -153,7 +159,7 @@ hipError_t run16_interleaved(Handle* h, const Problem<uint16_t, TOut>& p, const 
   const bool repack = p.m >= 32 && p.n >= 32 && flops >= 10.0 * moved;
   if (!repack) {
     h->last_kernel = SBAMD_KERNEL_INTERLEAVED;
-    return launch16_interleaved<Tag, TOut>(g, p.ta, p.tb, h->stream);
+    return launch16_interleaved<Tag, TOut>(g, p.ta, p.tb, h->stream, h->compute_units > 0 ? h->compute_units : 256);
   }
   const int64_t a_rows = p.ta ? p.k : p.m, a_cols = p.ta ? p.m : p.k;
   const int64_t b_rows = p.tb ? p.n : p.k, b_cols = p.tb ? p.k : p.n;

@@ -137,6 +137,18 @@ def test_long_batches_of_single_tile_items(sb_handle, dtype):
     assert sb_handle.last_kernel() == _lib.KERNEL_SMALL
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_interleaved_long_batches_take_the_big_register_block(sb_handle, dtype):
+    # Batches long enough to fill the chip with a quarter of the lanes run an 8 x 8 block of C per lane (the
+    # grids above, with their short batches, stay on 4 x 4): whole items, items with ragged edges in both
+    # dimensions, every transpose, beta == 0 and != 0, padded leading dimensions.  Same fma chain per element.
+    for (m, n, k, batch), (ta, tb) in itertools.product([(16, 16, 8, 33000), (17, 22, 5, 15000), (8, 16, 3, 66000)],
+                                                        [("n", "n"), ("t", "n"), ("n", "t"), ("t", "t")]):
+        verify_gemm(sb_handle, dtype, 0, batch, m, n, k, ta, tb, 1.5, 0.5, 1, 1, 1, batch_type=interleaved)
+        assert sb_handle.last_kernel() == _lib.KERNEL_INTERLEAVED
+    verify_gemm(sb_handle, dtype, 3, 22000, 16, 24, 7, "n", "t", -1.0, 0.0, 2, 3, 2, batch_type=interleaved)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
 def test_interleaved_alpha_zero_scales_every_item_once(sb_handle, dtype):
     # alpha == 0 on an interleaved batch: every item's m x n window is multiplied by beta once, the
