@@ -66,7 +66,7 @@ enum {
   SBAMD_KERNEL_LARGE = 1,    /* 128x128 macro tile, LDS double buffer      */
   SBAMD_KERNEL_SMALL = 2,    /* 64x64 macro tile (batched / small shapes)  */
   SBAMD_KERNEL_SPLITK = 3,   /* tall-skinny: K slabs -> cube -> reduction  */
-  SBAMD_KERNEL_NAIVE = 4,    /* one thread per C element, sequential k     */
+  SBAMD_KERNEL_NAIVE = 4,    /* one thread per C element, sequential k (chosen by itself for batches of items up to 16x16: a 4x4 block of C per thread) */
   SBAMD_KERNEL_HUGE = 5,     /* 256x256 (float) / 256x128 (double) macro tile */
   SBAMD_KERNEL_INTERLEAVED = 6, /* batch-contiguous layout; reported, not pinnable */
   SBAMD_KERNEL_TINY = 7,     /* 32x32 macro tile, one wavefront (batches of small matrices) */

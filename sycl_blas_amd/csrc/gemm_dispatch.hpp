@@ -223,6 +223,23 @@ hipError_t launch_interleaved(const GemmArgs<T>& g, bool ta, bool tb, hipStream_
   return launch_interleaved_tile<T, 4, 4>(g, ta, tb, stream);
 }
 
+// Batches of very small items: a 4 x 4 block of C per lane (gemm_block_kernel).
+template <typename T>
+hipError_t launch_block(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream) {
+  constexpr int IR = 4, IC = 4;
+  const int64_t total = ceil_div(g.m, IR) * ceil_div(g.n, IC) * g.batch;
+  const int64_t grid = ceil_div(total, 256);
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (ta) {
+    if (tb) hipLaunchKernelGGL((gemm_block_kernel<T, true, true, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_block_kernel<T, true, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  } else {
+    if (tb) hipLaunchKernelGGL((gemm_block_kernel<T, false, true, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_block_kernel<T, false, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  }
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_naive(const GemmArgs<T>& g, bool ta, bool tb, hipStream_t stream) {
   const int64_t total = g.m * g.n * g.batch;
@@ -512,7 +529,11 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   if (p.batch != 1 || plan.tile > TILE_256) plan.depth = 1;
   if (plan.tile == TILE_NAIVE) {
     h->last_kernel = SBAMD_KERNEL_NAIVE;
-    return launch_naive<T>(g, p.ta, p.tb, h->stream);
+    // pinned: one element per lane.  Chosen for a batch of very small items: its 4 x 4 register-block form once
+    // an item's C holds 512 bytes (fp32 16^3 x 65536: 162 -> 89 us, fp64 8^3 x 262144: 190 -> 140); below that
+    // the block form leaves too few lanes per item to keep their loads on shared cache lines (fp32 4^3: 64 -> 128 us)
+    if (h->kernel_override == SBAMD_KERNEL_NAIVE || p.m * p.n * int64_t(sizeof(T)) < 512) return launch_naive<T>(g, p.ta, p.tb, h->stream);
+    return launch_block<T>(g, p.ta, p.tb, h->stream);
   }
   if (plan.tile == TILE_32) {
     h->last_kernel = SBAMD_KERNEL_TINY;

@@ -1529,6 +1529,79 @@ __global__ void __launch_bounds__(256) gemm_naive_kernel(const GemmArgs<T> g) {
   *p = out;
 }
 
+// ------------------------------------- register-block kernel for batches of very small items
+// Strided batches of items of at most 16 x 16: one lane owns an IR x IC block of one item's C (the lanes of an
+// item are neighbours, so they share its cache lines) and walks k with fused multiply-adds -- per element the
+// same chain as the naive kernel, with IR + IC loads feeding IR * IC multiply-adds instead of two feeding one
+// (fp32 16^3 x 65536: 162 -> see the batch table of the design notes).
+template <typename T, bool TA, bool TB, int IR, int IC>
+__global__ void __launch_bounds__(256) gemm_block_kernel(const GemmArgs<T> g) {
+  const int64_t tiles_r = (g.m + IR - 1) / IR;
+  const int64_t tiles_c = (g.n + IC - 1) / IC;
+  const int64_t per = tiles_r * tiles_c;
+  const int64_t gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= per * g.batch) return;
+  const int64_t z = gid / per;
+  const int64_t t = gid - z * per;
+  const int64_t r0 = (t % tiles_r) * IR;
+  const int64_t c0 = (t / tiles_r) * IC;
+
+  T acc[IR][IC];
+#pragma unroll
+  for (int i = 0; i < IR; ++i)
+#pragma unroll
+    for (int j = 0; j < IC; ++j) acc[i][j] = T(0);
+
+  // clamped rows and columns feed unstored elements only
+  const T* pa[IR];
+  const T* pb[IC];
+#pragma unroll
+  for (int i = 0; i < IR; ++i) {
+    const int64_t r = r0 + i < g.m ? r0 + i : g.m - 1;
+    pa[i] = g.a + z * g.stride_a + (TA ? r * g.lda : r);
+  }
+#pragma unroll
+  for (int j = 0; j < IC; ++j) {
+    const int64_t c = c0 + j < g.n ? c0 + j : g.n - 1;
+    pb[j] = g.b + z * g.stride_b + (TB ? c : c * g.ldb);
+  }
+  const int64_t step_a = TA ? int64_t(1) : g.lda;
+  const int64_t step_b = TB ? g.ldb : int64_t(1);
+  for (int64_t k = 0; k < g.k; ++k) {
+    T av[IR], bv[IC];
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      av[i] = *pa[i];
+      pa[i] += step_a;
+    }
+#pragma unroll
+    for (int j = 0; j < IC; ++j) {
+      bv[j] = *pb[j];
+      pb[j] += step_b;
+    }
+#pragma unroll
+    for (int i = 0; i < IR; ++i)
+#pragma unroll
+      for (int j = 0; j < IC; ++j) acc[i][j] = fma_rn(av[i], bv[j], acc[i][j]);
+  }
+
+#pragma unroll
+  for (int j = 0; j < IC; ++j) {
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      if (r0 + i < g.m && c0 + j < g.n) {
+        T* p = g.c + z * g.stride_c + (r0 + i) + (c0 + j) * g.ldc;
+        T out = g.alpha * acc[i][j];
+        if (!g.beta_zero) {
+          const T bc = g.beta * (*p);
+          out = out + bc;
+        }
+        *p = out;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------- interleaved batched GEMM
 // Element (r, c) of batch item b lives at (r + c*ld)*batch + b, so the batch
 // index is the contiguous one (test/unittest/blas3/blas3_gemm_common.hpp:54-69).

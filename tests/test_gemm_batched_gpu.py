@@ -81,11 +81,13 @@ def test_config3_shape_sample(sb_handle):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
 def test_batches_of_tiny_matrices(sb_handle, dtype):
-    # Shapes the 64x64 tile would mostly pad: up to 16x16 takes one lane per C element, up to
-    # 32x32 the one-wave 32x32 tile; both keep the k-ordered chain (bitwise against the oracle).
+    # Shapes the 64x64 tile would mostly pad: up to 16x16 takes one lane per C element or, from 512 bytes of C
+    # per item on, a 4x4 block of C per lane (both reported as the NAIVE family), up to 32x32 the one-wave 32x32
+    # tile; all keep the k-ordered chain (bitwise against the oracle).
     sb_handle.set_kernel(_lib.KERNEL_AUTO)
     for (m, n, k, batch), want in [((4, 4, 4, 300), _lib.KERNEL_NAIVE), ((8, 8, 8, 64), _lib.KERNEL_NAIVE),
-                                   ((16, 9, 40, 17), _lib.KERNEL_NAIVE), ((17, 16, 16, 33), _lib.KERNEL_TINY),
+                                   ((16, 9, 40, 17), _lib.KERNEL_NAIVE), ((16, 16, 16, 40), _lib.KERNEL_NAIVE), ((13, 11, 7, 29), _lib.KERNEL_NAIVE),
+                                   ((17, 16, 16, 33), _lib.KERNEL_TINY),
                                    ((24, 24, 24, 50), _lib.KERNEL_TINY), ((32, 32, 100, 9), _lib.KERNEL_TINY),
                                    ((33, 32, 32, 9), _lib.KERNEL_SMALL)]:
         for ta, tb in itertools.product("nt", "nt"):
