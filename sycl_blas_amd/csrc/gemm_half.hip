@@ -143,6 +143,21 @@ hipError_t launch16_interleaved(const GemmArgs16<TOut>& g, bool ta, bool tb, hip
   return launch16_interleaved_tile<Tag, TOut, 4, 4>(g, ta, tb, stream);
 }
 
+template <typename Tag, typename TOut, int IR, int IC>
+hipError_t launch16_block(const GemmArgs16<TOut>& g, bool ta, bool tb, hipStream_t stream) {
+  const int64_t total = ceil_div(g.m, IR) * ceil_div(g.n, IC) * g.batch;
+  const int64_t grid = ceil_div(total, 256);
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (ta) {
+    if (tb) hipLaunchKernelGGL((gemm_block16_kernel<Tag, TOut, true, true, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_block16_kernel<Tag, TOut, true, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  } else {
+    if (tb) hipLaunchKernelGGL((gemm_block16_kernel<Tag, TOut, false, true, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_block16_kernel<Tag, TOut, false, false, IR, IC>), dim3((unsigned)grid), dim3(256), 0, stream, g);
+  }
+  return hipGetLastError();
+}
+
 template <typename Tag, typename TOut>
 hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float beta);
 
@@ -226,6 +241,13 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
   if (p.interleaved) return run16_interleaved<Tag, TOut>(h, p, g, alpha, beta);
 
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
+  // Batches of very small items: lane-level kernel, one element of C per lane or -- from 256 elements per item on --
+  // a 4 x 4 block (reported as the NAIVE family, like the fp32 / fp64 route for such batches).
+  if (p.batch > 1 && p.m <= 16 && p.n <= 16 && h->kernel_override == SBAMD_KERNEL_AUTO) {
+    h->last_kernel = SBAMD_KERNEL_NAIVE;
+    return p.m * p.n >= 256 ? launch16_block<Tag, TOut, 4, 4>(g, p.ta, p.tb, h->stream)
+                            : launch16_block<Tag, TOut, 1, 1>(g, p.ta, p.tb, h->stream);
+  }
   // The direct-to-LDS 256x256 kernel needs at least one whole K step, 16-byte vectors and no
   // vector straddling the matrix edge.
   bool dma_ok = g.vec_a && g.vec_b && p.k >= RING_BK && (p.ta || p.m % 8 == 0) && (!p.tb || p.n % 8 == 0);

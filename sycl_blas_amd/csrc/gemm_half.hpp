@@ -446,6 +446,78 @@ __global__ void __launch_bounds__(256) gemm_interleaved16_kernel(const GemmArgs1
   }
 }
 
+// Strided batches of very small 16-bit items (at most 16 x 16): the lanes of an item are neighbours, each owns an
+// IR x IC block of its C (1 x 1 or 4 x 4), operands widened to float, k in increasing order with fused multiply-adds:
+// the fp32 chain of the widened inputs rounded once, as in gemm_interleaved16_kernel.  A 64 x 64 matrix-instruction
+// tile per item would be almost all padding (half 16^3 x 65536: 218 us on it).
+template <typename Tag, typename TOut, bool TA, bool TB, int IR, int IC>
+__global__ void __launch_bounds__(256) gemm_block16_kernel(const GemmArgs16<TOut> g) {
+  const int64_t tiles_r = (g.m + IR - 1) / IR;
+  const int64_t tiles_c = (g.n + IC - 1) / IC;
+  const int64_t per = tiles_r * tiles_c;
+  const int64_t gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= per * g.batch) return;
+  const int64_t z = gid / per;
+  const int64_t t = gid - z * per;
+  const int64_t r0 = (t % tiles_r) * IR;
+  const int64_t c0 = (t / tiles_r) * IC;
+
+  float acc[IR][IC];
+#pragma unroll
+  for (int i = 0; i < IR; ++i)
+#pragma unroll
+    for (int j = 0; j < IC; ++j) acc[i][j] = 0.0f;
+
+  // clamped rows / columns only feed C elements that are never stored
+  const uint16_t* pa[IR];
+  const uint16_t* pb[IC];
+#pragma unroll
+  for (int i = 0; i < IR; ++i) {
+    const int64_t r = r0 + i < g.m ? r0 + i : g.m - 1;
+    pa[i] = g.a + z * g.stride_a + (TA ? r * g.lda : r);
+  }
+#pragma unroll
+  for (int j = 0; j < IC; ++j) {
+    const int64_t c = c0 + j < g.n ? c0 + j : g.n - 1;
+    pb[j] = g.b + z * g.stride_b + (TB ? c : c * g.ldb);
+  }
+  const int64_t step_a = TA ? int64_t(1) : g.lda;
+  const int64_t step_b = TB ? g.ldb : int64_t(1);
+  for (int64_t k = 0; k < g.k; ++k) {
+    float av[IR], bv[IC];
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      av[i] = widen(Tag{}, *pa[i]);
+      pa[i] += step_a;
+    }
+#pragma unroll
+    for (int j = 0; j < IC; ++j) {
+      bv[j] = widen(Tag{}, *pb[j]);
+      pb[j] += step_b;
+    }
+#pragma unroll
+    for (int i = 0; i < IR; ++i)
+#pragma unroll
+      for (int j = 0; j < IC; ++j) acc[i][j] = __builtin_fmaf(av[i], bv[j], acc[i][j]);
+  }
+
+#pragma unroll
+  for (int j = 0; j < IC; ++j) {
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      if (r0 + i < g.m && c0 + j < g.n) {
+        TOut* p = g.c + z * g.stride_c + (r0 + i) + (c0 + j) * g.ldc;
+        float out = g.alpha * acc[i][j];
+        if (!g.beta_zero) {
+          const float bc = g.beta * load_out(p);
+          out = out + bc;
+        }
+        store_out(p, out);
+      }
+    }
+  }
+}
+
 // C = beta * C for 16-bit output (alpha == 0 path): multiply in fp32, round once.
 __global__ void __launch_bounds__(256)
     scale_matrix16_kernel(uint16_t* c, int64_t rows, int64_t cols, int64_t ld, int64_t stride, int64_t batch,

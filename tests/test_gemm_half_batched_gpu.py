@@ -80,7 +80,7 @@ def verify_batched16(h, pair, offset, batch, m, n, k, ta, tb, alpha, beta, lda_m
     else:
         got_f, want_out = got_dev, want
     assert oracle.compare_vectors(got_f, want_out, out_name) == -1, what
-    if kernel == _lib.KERNEL_INTERLEAVED:
+    if kernel in (_lib.KERNEL_INTERLEAVED, _lib.KERNEL_NAIVE):
         assert np.array_equal(got_f.view(np.uint32), want_out.view(np.uint32)), what + ": not the fp32 chain"
 
     # accumulation bound around the float64 result, and untouched padding
@@ -147,6 +147,16 @@ def test_interleaved_long_batches_take_the_big_register_block(sb_handle, pair):
                                                         [("n", "n"), ("t", "n"), ("n", "t"), ("t", "t")]):
         assert verify_batched16(sb_handle, pair, 0, batch, m, n, k, ta, tb, 1.5, 0.5, 1, 1, 1, interleaved) == _lib.KERNEL_INTERLEAVED
     verify_batched16(sb_handle, pair, 3, 22000, 16, 24, 7, "n", "t", -1.0, 0.0, 2, 3, 2, interleaved)
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_strided_batches_of_tiny_items(sb_handle, pair):
+    # items of at most 16 x 16 in a strided batch run on lanes (one element or a 4 x 4 block of C per lane), not on a
+    # 64 x 64 matrix-instruction tile per item: the result is the fp32 chain of the widened inputs, rounded once
+    for (m, n, k, batch), (ta, tb) in itertools.product([(4, 4, 4, 300), (8, 8, 8, 64), (16, 9, 40, 17), (16, 16, 16, 40), (13, 11, 7, 29)],
+                                                        [("n", "n"), ("t", "n"), ("n", "t"), ("t", "t")]):
+        assert verify_batched16(sb_handle, pair, 3, batch, m, n, k, ta, tb, 1.5, 0.5, 2, 1, 2, strided) == _lib.KERNEL_NAIVE
+        verify_batched16(sb_handle, pair, 0, batch, m, n, k, ta, tb, -1.0, 0.0, 1, 1, 1, strided)
 
 
 @pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")

@@ -14,7 +14,8 @@ side = torch.cuda.Stream()
 torch.cuda.set_stream(side)
 h = C.c_void_p()
 assert lib.sbamd_create(C.byref(h), 0, C.c_void_p(side.cuda_stream)) == 0
-dt, fn, sc, isz = {"f32": (torch.float32, lib.sbamd_sgemm_batched, C.c_float, 4), "f64": (torch.float64, lib.sbamd_dgemm_batched, C.c_double, 8)}[name]
+dt, fn, sc, isz = {"f32": (torch.float32, lib.sbamd_sgemm_batched, C.c_float, 4), "f64": (torch.float64, lib.sbamd_dgemm_batched, C.c_double, 8),
+                   "f16": (torch.float16, lib.sbamd_hgemm_batched, C.c_float, 2)}[name]
 for (m, n, k, batch) in [(4, 4, 4, 1 << 20), (8, 8, 8, 1 << 18), (16, 16, 16, 1 << 16), (32, 32, 32, 1 << 13), (48, 48, 48, 4096),
                          (64, 64, 64, 4096), (96, 96, 96, 2048), (128, 128, 128, 1024), (256, 256, 256, 256), (512, 512, 512, 64),
                          (64, 64, 512, 2048), (32, 32, 1024, 4096), (100, 100, 100, 2000)]:
