@@ -41,6 +41,11 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef SBAMD_FAR_MAX_TILES
 #define SBAMD_FAR_MAX_TILES 1
 #endif
+// Lab switch (tools/step_lab.hip): 0 leaves the part of a K step behind its barrier to the compiler's scheduler
+// (the state before the fences and the pattern there were added), 1 is what the library is built with.
+#ifndef SBAMD_LAB_VARIANT
+#define SBAMD_LAB_VARIANT 1
+#endif
 
 // Arguments shared by every kernel in this file.  Pointers are typed in the
 // kernels; sizes are 64-bit so 65536 x 65536 operands index correctly.
@@ -465,9 +470,26 @@ struct GemmBody {
       else if (n < NWRITE + NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       if (n % STRIDE == 0) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
     }
+    // The pattern above only orders what it claims.  Left alone, hipcc moved a third of the matrix instructions
+    // of the last claimed group across the barrier and sank the next tile's first fragment reads to the bottom
+    // of the loop, right in front of the wait at its top.  Fences keep the barrier where it is written, and
+    // a second pattern puts one of those reads behind each of the first matrix instructions after it
+    // (8192^3: fp32 NT 143.3 -> 144.6-145.6 TFLOP/s, fp64 NN 73.3 -> 73.8-74.1, fp32 NN unchanged; fp64 64 x 64
+    // tile at 1024^3 51.7 -> 54.0).  Wavefront tiles of two matrix tiles (fp32 128 x 128 on eight wavefronts)
+    // stay as they were: NN 2048^3 lost 1.6 % with it.
+    constexpr bool PIN_TAIL = SBAMD_LAB_VARIANT >= 1 && K::MI * K::NI >= 4;
+    if (PIN_TAIL) __builtin_amdgcn_sched_barrier(0);
     if (!(SBAMD_ABLATE & 4)) __syncthreads();
+    if (PIN_TAIL) __builtin_amdgcn_sched_barrier(0);
     if (HAS_NEXT && !(SBAMD_ABLATE & 8)) fetch_group(nas, nbs, 0, a_mn, b_mn, lane, fa[0], fb[0]);
     mma_group(fa[(K::NGRP - 1) & 1], fb[(K::NGRP - 1) & 1]);
+    if (PIN_TAIL && HAS_NEXT) {
+#pragma unroll
+      for (int n = 0; n < NM; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        if (n < SLOTS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+      }
+    }
   }
 
   // ---- the pipelined path for one matrix tile per wavefront (64 x 64 workgroup tile, 32 x 32 tile) --------
