@@ -22,12 +22,23 @@
 #pragma once
 
 #include <type_traits>
+#include <utility>
 
 #include "gemm_half.hpp"
 
 namespace sbamd {
 
 constexpr int DMA_BM = 256, DMA_BN = 256, DMA_NT = 512;  // the big tile
+
+// f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>), in order
+template <int... Is, typename F>
+__device__ inline void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ inline void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 typedef __attribute__((address_space(1))) const void* dma_gptr_t;
 typedef __attribute__((address_space(3))) void* dma_lptr_t;
@@ -74,15 +85,16 @@ __device__ inline int ring_swizzle_mn(int krow) {
 
 template <bool KMAJOR, int ROWS = 256, int NT = DMA_NT, int SHAPE = 32>
 struct RingOperand {
-  static_assert(ROWS * 4 == 2 * NT, "two 16-byte pieces per thread and operand tile");
+  static constexpr int NP = ROWS * 4 / NT;  // 16-byte pieces per thread and operand tile
+  static_assert(ROWS * 4 == NP * NT && (NP == 2 || NP == 4), "two or four 16-byte pieces per thread and operand tile");
   static_assert(ROWS % 128 == 0, "the M/N-contiguous swizzle moves a piece by up to 12 positions inside its row");
   static constexpr int PER_KROW = ROWS / 8;  // pieces per k row of the M/N-contiguous image
   static constexpr int BYTES = ring_operand_bytes(ROWS);
-  const uint16_t* src[2];
+  const uint16_t* src[NP];
 
   __device__ inline void init(const uint16_t* __restrict__ x, int64_t ld, int64_t mn0, int64_t mn_lim, int tid) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int L = i * NT + tid;  // ROWS * 4 pieces per operand tile
       if (KMAJOR) {
         const int row = L >> 2;
@@ -108,8 +120,8 @@ struct RingOperand {
   }
   __device__ inline void advance(int64_t ld) {
     const int64_t step = KMAJOR ? int64_t(RING_BK) : int64_t(RING_BK) * ld;
-    src[0] += step;
-    src[1] += step;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) src[i] += step;
   }
 
   // Piece I of the K tail (k_rem = 1 .. 31 valid k behind the last whole K step, which is where the
@@ -168,15 +180,19 @@ struct RingOperand {
 
 // ABLATE is a timing-only diagnostic (bit 1: no loads inside the K loop, bit 2: no matrix
 // instructions, bit 4: no fragment reads); the library instantiates 0.
-// BM x BN tile on WM x WN wavefronts: 256 x 256 on 2 x 4 (wave tile 128 x 64) or 128 x 128 on 2 x 2 (64 x 64).
+// BM x BN tile on WM x WN wavefronts: 256 x 256 on 2 x 4 (wave tile 128 x 64) or on 2 x 2 (wave tile 128 x 128: one
+// wavefront per SIMD with 256 accumulator registers, a third fewer fragment bytes per flop), 128 x 128 on 2 x 2 (64 x 64).
 template <typename Tag, typename TOut, bool TA, bool TB, int ABLATE = 0, int BM = DMA_BM, int BN = DMA_BN, int WM = 2, int WN = 4>
-__global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const GemmArgs16<TOut> g) {
+__global__ void __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) > 128 * 64 ? 1 : 2)) gemm_mfma16_ring_kernel(const GemmArgs16<TOut> g) {
   constexpr int NT = WM * WN * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 32, NI = WTN / 32;
   constexpr int NM = MI * NI;  // matrix instructions per half step
   using OpA = RingOperand<TA, BM, NT>;
   using OpB = RingOperand<!TB, BN, NT>;
+  constexpr int NP = OpA::NP;   // load instructions per thread, operand and tile
+  constexpr int LPH = NP / 2;   // of them per half step
+  static_assert(OpA::NP == OpB::NP, "square tiles");
   constexpr int RING_OPERAND_BYTES = OpA::BYTES;  // offset of the B image inside a stage
   constexpr int RING_STAGE_BYTES = OpA::BYTES + OpB::BYTES;
 
@@ -236,16 +252,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const 
   for (int t = 0; t < RING_AHEAD; ++t) {
     if (t < nk) {
       SBAMD_LDS unsigned char* st = smem + t * RING_STAGE_BYTES;
-      oa.template issue_piece<0>(st, wave);
-      oa.template issue_piece<1>(st, wave);
-      ob.template issue_piece<0>(st + RING_OPERAND_BYTES, wave);
-      ob.template issue_piece<1>(st + RING_OPERAND_BYTES, wave);
+      static_for<NP>([&](auto i) { oa.template issue_piece<decltype(i)::value>(st, wave); });
+      static_for<NP>([&](auto i) { ob.template issue_piece<decltype(i)::value>(st + RING_OPERAND_BYTES, wave); });
       oa.advance(g.lda);
       ob.advance(g.ldb);
     }
   }
-  // tile 0 must have landed for every wave before anyone reads it
-  if (nk > RING_AHEAD - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  // tile 0 must have landed for every wave before anyone reads it (three more tiles of 2 * NP loads may be in flight)
+  if (nk > RING_AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NP) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -274,35 +288,27 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const 
       if constexpr (!(ABLATE & 2)) acc[I][J] = Mfma16<Tag>::mma(cb[J], ca[I], acc[I][J]);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (READS && N < MI + NI && !(ABLATE & 4)) read_unit(std::integral_constant<int, N>{}, s_next_tag, st_next, na, nb);
-      if constexpr (LOADS && N == NM / 4 && !(ABLATE & 1)) oa.template issue_piece<PIECE>(fill, wave);
-      if constexpr (LOADS && N == NM / 2 + NM / 4 - (NM > 4 ? 1 : 0) && !(ABLATE & 1)) ob.template issue_piece<PIECE>(fill + RING_OPERAND_BYTES, wave);
+      if constexpr (LOADS && !(ABLATE & 1)) {
+        // this half step's load instructions (A's LPH pieces, then B's) behind matrix instructions 2 and 5 of
+        // eight, 1 and 3 of four, 2 / 6 / 10 / 14 of sixteen
+        static_for<2 * LPH>([&](auto l_tag) {
+          constexpr int L = decltype(l_tag)::value;
+          constexpr int AT = NP == 2 ? (L == 0 ? NM / 4 : NM / 2 + NM / 4 - (NM > 4 ? 1 : 0)) : (2 * L + 1) * NM / (4 * LPH);
+          if constexpr (N == AT) {
+            if constexpr (L < LPH) oa.template issue_piece<PIECE * LPH + L>(fill, wave);
+            else ob.template issue_piece<PIECE * LPH + L - LPH>(fill + RING_OPERAND_BYTES, wave);
+          }
+        });
+      }
       __builtin_amdgcn_sched_barrier(0);
     };
-    slot(std::integral_constant<int, 0>{});
-    slot(std::integral_constant<int, 1>{});
-    slot(std::integral_constant<int, 2>{});
-    slot(std::integral_constant<int, 3>{});
-    if constexpr (NM > 4) {
-      slot(std::integral_constant<int, 4>{});
-      slot(std::integral_constant<int, 5>{});
-      slot(std::integral_constant<int, 6>{});
-      slot(std::integral_constant<int, 7>{});
-    }
+    static_for<NM>(slot);
   };
-  // load pieces behind matrix instructions 2 and 5 of eight, 1 and 3 of four
-  static_assert((NM == 8 || NM == 4) && MI + NI <= NM, "the slot list above is written for wave tiles of 128 x 64 and 64 x 64");
+  static_assert((NM == 16 || NM == 8 || NM == 4) && MI + NI <= NM, "wave tiles of 128 x 128, 128 x 64 and 64 x 64");
 
   // first fragments of tile 0
   {
-    auto all = [&](auto u) { read_unit(u, std::integral_constant<int, 0>{}, smem, fa[0], fb[0]); };
-    all(std::integral_constant<int, 0>{});
-    all(std::integral_constant<int, 1>{});
-    all(std::integral_constant<int, 2>{});
-    all(std::integral_constant<int, 3>{});
-    if constexpr (MI + NI > 4) {
-      all(std::integral_constant<int, 4>{});
-      all(std::integral_constant<int, 5>{});
-    }
+    static_for<MI + NI>([&](auto u) { read_unit(u, std::integral_constant<int, 0>{}, smem, fa[0], fb[0]); });
   }
 
   // One K step.  LOADS: tile t + RING_AHEAD exists and is issued here; NEXT: tile
@@ -321,7 +327,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const 
               fa[1], fb[1]);
 
     // every fragment read of tile t has returned; own pieces of tile t + 1 have landed
-    if (LOADS && !(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    // (in flight and allowed to stay so: tiles t + 2, t + 3 and the first half of tile t + 4, 5 * NP loads)
+    if (LOADS && !(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(5 * NP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -357,23 +364,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_ring_kernel(const 
   const int k_rem = int(k_len - int64_t(nk) * RING_BK);
   if (k_rem > 0) {
     __syncthreads();
-    const u16x8 a0 = oa.template load_tail<0>(k_rem, tid), a1 = oa.template load_tail<1>(k_rem, tid);
-    const u16x8 b0 = ob.template load_tail<0>(k_rem, tid), b1 = ob.template load_tail<1>(k_rem, tid);
-    OpA::template store_tail<0>(smem, tid, a0);
-    OpA::template store_tail<1>(smem, tid, a1);
-    OpB::template store_tail<0>(smem + RING_OPERAND_BYTES, tid, b0);
-    OpB::template store_tail<1>(smem + RING_OPERAND_BYTES, tid, b1);
+    u16x8 ta[NP], tb[NP];
+    static_for<NP>([&](auto i) { ta[decltype(i)::value] = oa.template load_tail<decltype(i)::value>(k_rem, tid); });
+    static_for<NP>([&](auto i) { tb[decltype(i)::value] = ob.template load_tail<decltype(i)::value>(k_rem, tid); });
+    static_for<NP>([&](auto i) { OpA::template store_tail<decltype(i)::value>(smem, tid, ta[decltype(i)::value]); });
+    static_for<NP>([&](auto i) { OpB::template store_tail<decltype(i)::value>(smem + RING_OPERAND_BYTES, tid, tb[decltype(i)::value]); });
     __syncthreads();
     auto tail_half = [&](auto s_tag) {
-      auto all = [&](auto u) { read_unit(u, s_tag, smem, fa[0], fb[0]); };
-      all(std::integral_constant<int, 0>{});
-      all(std::integral_constant<int, 1>{});
-      all(std::integral_constant<int, 2>{});
-      all(std::integral_constant<int, 3>{});
-      if constexpr (MI + NI > 4) {
-        all(std::integral_constant<int, 4>{});
-        all(std::integral_constant<int, 5>{});
-      }
+      static_for<MI + NI>([&](auto u) { read_unit(u, s_tag, smem, fa[0], fb[0]); });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposing reads are not tracked by the compiler
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

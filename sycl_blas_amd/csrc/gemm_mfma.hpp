@@ -463,11 +463,18 @@ struct GemmBody {
     constexpr int SLOTS = K::MI + K::NI;
     constexpr int STRIDE = NM / SLOTS > 0 ? NM / SLOTS : 1;
     constexpr int PER = SLOTS / NM > 0 ? SLOTS / NM : 1;
+    // LDS store instructions the pattern claims: the caller's count, except that a K-contiguous fp32 operand is
+    // written with four 4-byte stores per vector, not two 8-byte ones (claiming all of them: 8192^3 NN on the
+    // 256 x 256 tile 145.4 -> 146.5-146.8 TFLOP/s; the 128 x 128 tile on eight wavefronts measured no gain and keeps
+    // the caller's count).
+    constexpr int NWR = (NWRITE > 0 && K::MI * K::NI >= 4)
+                            ? LoadA::NV * ((TA && M::V == 4) ? 4 : 1) + LoadB::NV * ((!TB && M::V == 4) ? 4 : 1)
+                            : NWRITE;
 #pragma unroll
     for (int n = 0; n < (K::NGRP - 1) * NM; ++n) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (n < NWRITE) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      else if (n < NWRITE + NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (n < NWR) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      else if (n < NWR + NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       if (n % STRIDE == 0) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
     }
     // The pattern above only orders what it claims.  Left alone, hipcc moved a third of the matrix instructions

@@ -44,15 +44,16 @@ void add_variants(std::vector<Variant>& v) {
                    hipLaunchKernelGGL(k, dim3(h.tiles_m * h.tiles_n), dim3(256), lds, 0, h);
                  }, false, {}});
   }
-  auto add_ring = [&](const char* name, auto kernel, bool check) {
+  auto add_ring = [&](const char* name, auto kernel, bool check, int threads = DMA_NT) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
-    v.push_back({name, [kernel](const GemmArgs16<float>& g) {
+    v.push_back({name, [kernel, threads](const GemmArgs16<float>& g) {
                    GemmArgs16<float> h = g;
                    h.tiles_m = int((g.m + 255) / 256), h.tiles_n = int((g.n + 255) / 256);
-                   hipLaunchKernelGGL(kernel, dim3(h.tiles_m * h.tiles_n), dim3(DMA_NT), RING_LDS_BYTES, 0, h);
+                   hipLaunchKernelGGL(kernel, dim3(h.tiles_m * h.tiles_n), dim3(threads), RING_LDS_BYTES, 0, h);
                  }, check, {}});
   };
   add_ring("256x256 ring (5 x BK32)", gemm_mfma16_ring_kernel<Bf16Tag, float, TA, TB, 0>, true);
+  add_ring("256x256 ring, 4 waves of 128x128", gemm_mfma16_ring_kernel<Bf16Tag, float, TA, TB, 0, 256, 256, 2, 2>, true, 256);
 #ifdef LAB_ABLATE
   add_ring("ring, no loads in loop", gemm_mfma16_ring_kernel<Bf16Tag, float, TA, TB, 1>, false);
   add_ring("ring, no mfma", gemm_mfma16_ring_kernel<Bf16Tag, float, TA, TB, 2>, false);
