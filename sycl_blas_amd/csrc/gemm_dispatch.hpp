@@ -123,13 +123,16 @@ hipError_t launch_stream_nt(const GemmArgs<T>& g, int cus, hipStream_t stream) {
                                int(lds));
   });
   if (e != hipSuccess) return e;
-  const int64_t grid = std::min<int64_t>(g.batch, int64_t(cus) * OCC);
+  const int64_t items = g.tiles_m > 0 ? int64_t(g.tiles_m) * int64_t(g.tiles_n) : int64_t(g.batch);
+  const int64_t grid = std::min<int64_t>(items, int64_t(cus) * OCC);
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, stream, g);
   return hipGetLastError();
 }
 
 template <typename T, int BK, int OCC, bool TA, bool TB, bool READ_C>
 hipError_t launch_stream_one(const GemmArgs<T>& g, int cus, hipStream_t stream) {
+  // the tile walk re-reads its operand panels out of the L2: never non-temporal
+  if (g.tiles_m > 0) return launch_stream_nt<T, BK, OCC, TA, TB, READ_C, false>(g, cus, stream);
   // operands that will not stay in the Infinity Cache anyway are loaded non-temporally
   const double bytes = double(g.batch) * sizeof(T) *
                        (double(g.m) * double(g.k) + double(g.k) * double(g.n) + (READ_C ? 2.0 : 1.0) * double(g.m) * double(g.n));
@@ -505,6 +508,24 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   }
 
   const int cus = h->compute_units > 0 ? h->compute_units : 256;
+
+  // One product with K equal to the one-shot K step and many 64 x 64 tiles (rank-64 updates, 8192 x 8192 x 64):
+  // bound by writing C.  A fixed set of workgroups walks the tiles with the next tile's operand panels in
+  // flight during the current tile's matrix work and C stores (gemm_batch_stream_kernel's tile walk).  Measured
+  // at 8192 x 8192 x 64 against the 256-wide tile: beta != 0 (C read and written) fp32 321 -> 136 us, fp64
+  // 466 -> 294 us; beta == 0 the same 113 / 220 us (both then run at the clock the chip holds while it writes
+  // 2.4 TB/s).  Same k-ordered chain per element, same bits.
+  if (h->kernel_override == SBAMD_KERNEL_AUTO && p.batch == 1 && p.k == Tiles<T>::ONESHOT_BK && p.m % 64 == 0 &&
+      p.n % 64 == 0 && g.vec_a && g.vec_b && std::max({p.lda, p.ldb, p.ldc}) < (int64_t(1) << 22) &&
+      (p.m / 64) * (p.n / 64) >= 2 * int64_t(cus) * Tiles<T>::STREAM_OCC && p.m / 64 < (int64_t(1) << 30) &&
+      p.n / 64 < (int64_t(1) << 30)) {
+    g.tiles_m = int32_t(p.m / 64);
+    g.tiles_n = int32_t(p.n / 64);
+    h->last_kernel = SBAMD_KERNEL_STREAM;
+    h->last_depth = 1;
+    h->last_k_chunk = p.k;
+    return launch_stream<T, Tiles<T>::ONESHOT_BK, Tiles<T>::STREAM_OCC>(g, p.ta, p.tb, cus, h->stream);
+  }
 
   Plan plan = plan_gemm<T>(p.m, p.n, p.k, p.batch, cus);
   // A pinned family overrides the planner (testing / tuning hook).

@@ -1312,10 +1312,31 @@ __global__ void __launch_bounds__(256, OCC)
   const int b_mn = wn * K::WTN + frag_mn;
   const T alpha = g.alpha, beta = g.beta;
 
+  // Tile walk (g.tiles_m > 0): the items are the BMN x BMN tiles of ONE product whose K is the K step (the
+  // host checks that M and N are multiples of BMN) -- tile (tm, tn) reads row panel tm of A and column panel
+  // tn of B, which stay in the L2 (the panels of a whole 8192 x 8192 x 64 product are 4 MB), and the walk is
+  // bound by writing C once; the next tile's panels are requested before the current tile's matrix work
+  // and its C stores drain while the next tile is multiplied, which a launch of one workgroup per tile
+  // (or one per compute unit) does not overlap.
+  const bool walk = g.tiles_m > 0;
+  const int64_t nitems = walk ? int64_t(g.tiles_m) * int64_t(g.tiles_n) : int64_t(g.batch);
+  auto item_a = [&](int64_t item) -> const T* {
+    if (!walk) return g.a + item * g.stride_a;
+    return g.a + (item % g.tiles_m) * BMN * (TA ? g.lda : int64_t(1));
+  };
+  auto item_b = [&](int64_t item) -> const T* {
+    if (!walk) return g.b + item * g.stride_b;
+    return g.b + (item / g.tiles_m) * BMN * (TB ? int64_t(1) : g.ldb);
+  };
+  auto item_c = [&](int64_t item) -> T* {
+    if (!walk) return g.c + item * g.stride_c;
+    return g.c + (item % g.tiles_m) * BMN + (item / g.tiles_m) * BMN * g.ldc;
+  };
+
   // Where a thread's vectors sit inside an item does not depend on the item: 32-bit byte
   // offsets computed once, added to the item's (uniform) base address by the load itself.
   // Rows / vectors past the edge point at the last valid one, as in the tile kernel.
-  const uint32_t m = uint32_t(g.m), n = uint32_t(g.n);
+  const uint32_t m = walk ? uint32_t(BMN) : uint32_t(g.m), n = walk ? uint32_t(BMN) : uint32_t(g.n);
   const uint32_t lda = uint32_t(g.lda), ldb = uint32_t(g.ldb), ldc = uint32_t(g.ldc);
   uint32_t offa[LoadA::NV], offb[LoadB::NV];
 #pragma unroll
@@ -1341,9 +1362,9 @@ __global__ void __launch_bounds__(256, OCC)
   constexpr int RANGE = 0x7fffffff;
   auto request = [&](int64_t item) {
     const __amdgpu_buffer_rsrc_t ra =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.a + item * g.stride_a), 0, RANGE, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(item_a(item)), 0, RANGE, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g.b + item * g.stride_b), 0, RANGE, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(item_b(item)), 0, RANGE, 0x00020000);
 #pragma unroll
     for (int i = 0; i < LoadA::NV; ++i) {
       const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(ra, int(offa[i]), 0, NT_LOADS ? 2 : 0);
@@ -1376,14 +1397,14 @@ __global__ void __launch_bounds__(256, OCC)
   };
 
   int64_t z = blockIdx.x;
-  if (z >= g.batch) return;  // uniform over the workgroup
+  if (z >= nitems) return;  // uniform over the workgroup
   request(z);
 
   for (;;) {
     body.la.store(smem, tid);
     body.lb.store(smem + K::A_ELEMS, tid);
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.c + z * g.stride_c, 0, RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(item_c(z), 0, RANGE, 0x00020000);
     // beta * C operands first, then the next item's tiles: the memory counter retires
     // in order, so the epilogue can wait for the former while the latter stay in flight.
     T cin[K::MI][K::NI][M::NACC];
@@ -1396,7 +1417,11 @@ __global__ void __launch_bounds__(256, OCC)
           for (int r = 0; r < M::NACC; ++r) cin[i][j][r] = c_load(rc, c_offset(i, j, r));
     }
     const int64_t zn = z + gridDim.x;
-    if (zn < g.batch) request(zn);
+#ifdef SBAMD_WALK_ABLATE
+    if (zn < nitems && !(SBAMD_WALK_ABLATE & 2)) request(zn);
+#else
+    if (zn < nitems) request(zn);
+#endif
     __builtin_amdgcn_sched_barrier(0);  // the requests go out before the matrix work
 #pragma unroll
     for (int i = 0; i < K::MI; ++i)
@@ -1404,6 +1429,9 @@ __global__ void __launch_bounds__(256, OCC)
       for (int j = 0; j < K::NI; ++j)
 #pragma unroll
         for (int r = 0; r < M::NACC; ++r) body.acc[i][j][r] = T(0);
+#ifdef SBAMD_WALK_ABLATE
+    if (!(SBAMD_WALK_ABLATE & 4))
+#endif
     body.template compute<0>(smem, smem + K::A_ELEMS, a_mn, b_mn, lane);
 #pragma unroll
     for (int i = 0; i < K::MI; ++i)
@@ -1416,9 +1444,12 @@ __global__ void __launch_bounds__(256, OCC)
             const T bc = beta * cin[i][j][r];
             out = out + bc;
           }
+#ifdef SBAMD_WALK_ABLATE
+          if ((SBAMD_WALK_ABLATE & 1) && zn < nitems) continue;  // only the last tile of a workgroup is stored
+#endif
           c_store(rc, c_offset(i, j, r), out);
         }
-    if (zn >= g.batch) break;
+    if (zn >= nitems) break;
     z = zn;
     __syncthreads();  // every wave is done with the fragments before the stage is overwritten
   }

@@ -197,3 +197,24 @@ def test_operand_tiles_straight_into_lds(sb_handle, offset):
         assert h.last_splitk()[0] == 3
     finally:
         h.set_kernel(_lib.KERNEL_AUTO)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_short_k_products_walk_their_tiles(sb_handle, dtype):
+    # One product with K = 64 and more 64 x 64 tiles of C than the chip holds workgroups twice over: resident
+    # workgroups walk the tiles with the next tile's operand panels in flight (the batch-walking kernel with
+    # tile addressing).  Same k-ordered chain per element as the tile kernels: whole buffers (the padding of a
+    # multiplied leading dimension included) must equal the oracle bit for bit, for every transpose, with C
+    # read and not read, at an offset that keeps the operands 16-byte aligned.
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    v = 16 // np.dtype(dtype).itemsize
+    m, n = (4096, 2048) if dtype == np.float32 else (2048, 2048)
+    for ta, tb in itertools.product("nt", "nt"):
+        verify_gemm(sb_handle, dtype, 0, 1, m, n, 64, ta, tb, 1.5, 0.0, 1, 1, 1)
+        assert sb_handle.last_kernel() == _lib.KERNEL_STREAM
+        verify_gemm(sb_handle, dtype, 2 * v, 1, m, n + 64, 64, ta, tb, -1.0, 0.75, 2, 1, 2)
+        assert sb_handle.last_kernel() == _lib.KERNEL_STREAM
+    # what the walk does not take keeps the tile kernels: a ragged edge, another K, unaligned operands, too few tiles
+    for args in ((0, 1, m - 4, n, 64), (0, 1, m, n, 96), (1, 1, m, n, 64), (0, 1, 1024, 1024, 64)):
+        verify_gemm(sb_handle, dtype, *args, "n", "n", 1.0, 0.5, 1, 1, 1)
+        assert sb_handle.last_kernel() != _lib.KERNEL_STREAM
