@@ -325,27 +325,15 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) gemm_mfma16_kernel(const GemmA
   }
 
   // epilogue in fp32: out = alpha*acc (+ beta*C), rounded once to the output type
-  const bool read_c = !g.beta_zero;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int64_t mm = m0 + a_row + i * 32;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+  store_tiles<MI, NI, 16, float>(
+      !g.beta_zero, g.beta,
+      [&](int i, int j, int r) -> TOut* {
+        const int64_t mm = m0 + a_row + i * 32;
         const int64_t nn = n0 + wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_h;
-        if (mm < g.m && nn < g.n) {
-          TOut* p = c + mm + nn * g.ldc;
-          float out = g.alpha * acc[i][j][r];
-          if (read_c) {
-            const float bc = g.beta * load_out(p);
-            out = out + bc;
-          }
-          store_out(p, out);
-        }
-      }
-    }
-  }
+        return (mm < g.m && nn < g.n) ? c + mm + nn * g.ldc : nullptr;
+      },
+      [&](int i, int j, int r) -> float { return g.alpha * acc[i][j][r]; },
+      [](const TOut* p) -> float { return load_out(p); }, [](TOut* p, float v) { store_out(p, v); });
 }
 
 // Sum of the K slabs (fp32 cube, slabs added in index order) + beta * C, rounded once to

@@ -384,28 +384,22 @@ __global__ void __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) > 128 * 64
     if (k_rem > 16) tail_half(std::integral_constant<int, 1>{});
   }
 
-  const bool read_c = !g.beta_zero;
   const int frag_mn = lane & 31, frag_h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int64_t mm = m0 + wm * WTM + i * 32 + frag_mn;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t nn = n0 + wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_h;
-        if (mm < g.m && nn < g.n) {
-          TOut* p = c + mm + nn * g.ldc;
-          float out = g.alpha * acc[i][j][r];
-          if (read_c) {
-            const float bc = g.beta * load_out(p);
-            out = out + bc;
-          }
-          store_out(p, out);
-        }
-      }
-    }
+  auto value = [&](int i, int j, int r) -> float { return g.alpha * acc[i][j][r]; };
+  if (m0 + BM <= g.m && n0 + BN <= g.n && g.ldc * int64_t(WTN * sizeof(TOut)) < (int64_t(1) << 31)) {
+    store_tiles_interior<MI, NI, 16, 32, float, TOut>(
+        !g.beta_zero, g.beta, c + (m0 + wm * WTM) + (n0 + wn * WTN) * g.ldc, g.ldc, frag_mn, 4 * frag_h,
+        [](int r) { return (r & 3) + 8 * (r >> 2); }, value);
+    return;
   }
+  store_tiles<MI, NI, 16, float>(
+      !g.beta_zero, g.beta,
+      [&](int i, int j, int r) -> TOut* {
+        const int64_t mm = m0 + wm * WTM + i * 32 + frag_mn;
+        const int64_t nn = n0 + wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_h;
+        return (mm < g.m && nn < g.n) ? c + mm + nn * g.ldc : nullptr;
+      },
+      value, [](const TOut* p) -> float { return load_out(p); }, [](TOut* p, float v) { store_out(p, v); });
 }
 
 

@@ -862,6 +862,103 @@ struct GemmBody {
   }
 };
 
+// Epilogue of the tile kernels: C <- value (+ beta * C) for the MI x NI matrix tiles of a wavefront, NACC
+// elements per lane and tile.  ptr(i, j, r) is the element's address, or nullptr past the edge of C;
+// value(i, j, r) is alpha * (its sum).  The products and the sum round separately (-ffp-contract=off).
+// Element by element (load, add, store, next load): every load sits behind a store to memory the compiler
+// cannot tell apart from it, so with C read each element costs a memory round trip.  Tiles at the edge of C
+// and 16-bit outputs live with that; interior tiles take store_tiles_interior below.
+template <int MI, int NI, int NACC, typename V, typename PtrF, typename ValF, typename LoadF, typename StoreF>
+__device__ inline void store_tiles(bool read_c, V beta, PtrF&& ptr, ValF&& value, LoadF&& load, StoreF&& store) {
+#pragma unroll
+  for (int t = 0; t < MI * NI; ++t)
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+      auto* p = ptr(t / NI, t % NI, r);
+      if (p) {
+        V out = value(t / NI, t % NI, r);
+        if (read_c) {
+          const V bc = beta * load(p);
+          out = out + bc;
+        }
+        store(p, out);
+      }
+    }
+}
+
+// The same epilogue for a wavefront tile that lies wholly inside C (elements of 2, 4 or 8 bytes in memory; 2-byte
+// elements are halves, widened to / rounded from the float the arithmetic runs in).  Addresses are a
+// wave-uniform buffer descriptor at the tile's origin, one 32-bit per-lane byte offset (the lane's row and its
+// share of the column index) and a scalar offset per element (the rest of the column index times ldc): no
+// 64-bit address per element, no exec-mask branch.  With C read, the loads of the next batch of 16 (8-byte
+// elements: 8) are issued before the current batch is stored, so a lane has a batch of loads in flight instead
+// of one (SGEMM 8192 x 8192 x 256, beta != 0: 518 us element by element against 284 us with beta == 0).
+// `origin` must be wave-uniform; lane_row = the lane's row inside the tile, lane_col = its column share
+// (acc_i(0, lane)), col_of(r) = acc_i(r, 0); the caller checks WTN * ldc * sizeof(TMem) < 2^31.
+template <int MI, int NI, int NACC, int MT, typename V, typename TMem, typename ColF, typename ValF>
+__device__ inline void store_tiles_interior(bool read_c, V beta, TMem* origin, int64_t ldc, int lane_row, int lane_col,
+                                            ColF&& col_of, ValF&& value) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  static_assert(sizeof(TMem) == sizeof(V) || (sizeof(TMem) == 2 && sizeof(V) == 4), "same type, or halves behind floats");
+  static_assert(sizeof(V) == 4 || sizeof(V) == 8, "4- or 8-byte arithmetic");
+  constexpr int E = MI * NI * NACC;
+  constexpr int B = sizeof(V) == 4 ? 16 : 8;  // elements per batch
+  static_assert(E % B == 0, "whole batches");
+  // (readfirstlane returns a signed int: widen through uint32_t, or a low half with its top bit set smears
+  // ones over the high half)
+  const uint32_t origin_hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(origin) >> 32))));
+  const uint32_t origin_lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(origin)))));
+  const uint64_t uniform = (uint64_t(origin_hi) << 32) | uint64_t(origin_lo);
+  const __amdgpu_buffer_rsrc_t rc =
+      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<TMem*>(uniform), 0, 0x7fffffff, 0x00020000);
+  const int ldc_bytes = int(ldc) * int(sizeof(TMem));
+  const int voff0 = lane_row * int(sizeof(TMem)) + lane_col * ldc_bytes;
+  auto voff = [&](int e) { return voff0 + ((e / NACC) / NI) * MT * int(sizeof(TMem)); };
+  auto soff = [&](int e) { return (((e / NACC) % NI) * MT + col_of(e % NACC)) * ldc_bytes; };
+  auto load = [&](int e) -> V {
+    if constexpr (sizeof(TMem) == 2) {
+      const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(rc, voff(e), soff(e), 0);
+      return V(__builtin_bit_cast(_Float16, h));
+    } else if constexpr (sizeof(V) == 4) {
+      return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(rc, voff(e), soff(e), 0));
+    } else {
+      return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(rc, voff(e), soff(e), 0));
+    }
+  };
+  auto store = [&](int e, V v) {
+    if constexpr (sizeof(TMem) == 2)
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, _Float16(v)), rc, voff(e), soff(e), 0);
+    else if constexpr (sizeof(V) == 4)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rc, voff(e), soff(e), 0);
+    else
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rc, voff(e), soff(e), 0);
+  };
+  auto val = [&](int e) -> V { return value((e / NACC) / NI, (e / NACC) % NI, e % NACC); };
+  if (!read_c) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) store(e, val(e));
+    return;
+  }
+  V cin[2][B];
+#pragma unroll
+  for (int q = 0; q < B; ++q) cin[0][q] = load(q);
+#pragma unroll
+  for (int b0 = 0; b0 < E; b0 += B) {
+    const int cur = (b0 / B) & 1;
+    if (b0 + B < E) {
+#pragma unroll
+      for (int q = 0; q < B; ++q) cin[cur ^ 1][q] = load(b0 + B + q);
+    }
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      V out = val(b0 + q);
+      const V bc = beta * cin[cur][q];
+      out = out + bc;
+      store(b0 + q, out);
+    }
+  }
+}
+
 // OCC = waves per SIMD the register allocation must leave room for.
 template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC>
 __global__ void __launch_bounds__(WM* WN * 64, OCC)
@@ -926,28 +1023,23 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 
   // ---- epilogue: C = alpha * acc (+ beta * C); products and the sum round
   // separately (the file is built with -ffp-contract=off).
-  const T alpha = g.alpha, beta = g.beta;
+  const T alpha = g.alpha;
   const bool read_c = !g.beta_zero && g.split_k <= 1;
-#pragma unroll
-  for (int i = 0; i < K::MI; ++i) {
-    const int64_t mm = m0 + a_mn + i * M::T;
-#pragma unroll
-    for (int j = 0; j < K::NI; ++j) {
-#pragma unroll
-      for (int r = 0; r < M::NACC; ++r) {
-        const int64_t nn = n0 + wn * K::WTN + j * M::T + M::acc_i(r, lane);
-        if (mm < g.m && nn < g.n) {
-          T* p = c + mm + nn * g.ldc;
-          T out = alpha * body.acc[i][j][r];
-          if (read_c) {
-            const T bc = beta * (*p);
-            out = out + bc;
-          }
-          *p = out;
-        }
-      }
-    }
+  auto value = [&](int i, int j, int r) -> T { return alpha * body.acc[i][j][r]; };
+  if (interior && g.ldc * int64_t(K::WTN * sizeof(T)) < (int64_t(1) << 31)) {
+    store_tiles_interior<K::MI, K::NI, M::NACC, M::T, T, T>(
+        read_c, g.beta, c + (m0 + wm * K::WTM) + (n0 + wn * K::WTN) * g.ldc, g.ldc, frag_mn, M::acc_i(0, lane),
+        [](int r) { return M::acc_i(r, 0); }, value);
+    return;
   }
+  store_tiles<K::MI, K::NI, M::NACC, T>(
+      read_c, g.beta,
+      [&](int i, int j, int r) -> T* {
+        const int64_t mm = m0 + a_mn + i * M::T;
+        const int64_t nn = n0 + wn * K::WTN + j * M::T + M::acc_i(r, lane);
+        return (mm < g.m && nn < g.n) ? c + mm + nn * g.ldc : nullptr;
+      },
+      value, [](const T* p) -> T { return *p; }, [](T* p, T v) { *p = v; });
 }
 
 // ------------------------------------------ two K halves in one workgroup
@@ -1029,28 +1121,18 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
   }
   __syncthreads();
   if (half == 1) return;
-  const bool read_c = !g.beta_zero;
-#pragma unroll
-  for (int i = 0; i < K::MI; ++i) {
-    const int64_t mm = m0 + a_mn + i * M::T;
-#pragma unroll
-    for (int j = 0; j < K::NI; ++j) {
-#pragma unroll
-      for (int r = 0; r < M::NACC; ++r) {
+  store_tiles<K::MI, K::NI, M::NACC, T>(
+      !g.beta_zero, beta,
+      [&](int i, int j, int r) -> T* {
+        const int64_t mm = m0 + a_mn + i * M::T;
         const int64_t nn = n0 + wn * K::WTN + j * M::T + M::acc_i(r, lane);
+        return (mm < g.m && nn < g.n) ? c + mm + nn * g.ldc : nullptr;
+      },
+      [&](int i, int j, int r) -> T {
         const T first = alpha * body.acc[i][j][r];
-        T out = first + slot[((i * K::NI + j) * M::NACC + r) * 64];
-        if (mm < g.m && nn < g.n) {
-          T* p = c + mm + nn * g.ldc;
-          if (read_c) {
-            const T bc = beta * (*p);
-            out = out + bc;
-          }
-          *p = out;
-        }
-      }
-    }
-  }
+        return first + slot[((i * K::NI + j) * M::NACC + r) * 64];
+      },
+      [](const T* p) -> T { return *p; }, [](T* p, T v) { *p = v; });
 }
 
 // ------------------------------------------- operand tiles straight into LDS (fp32)
@@ -1254,28 +1336,17 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     }
   }
 
-  const float alpha = g.alpha, beta = g.beta;
+  const float alpha = g.alpha;
   const bool read_c = !g.beta_zero && g.split_k <= 1;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int64_t mm = m0 + a_mn + i * 32;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+  store_tiles<MI, NI, 16, float>(
+      read_c, g.beta,
+      [&](int i, int j, int r) -> float* {
+        const int64_t mm = m0 + a_mn + i * 32;
         const int64_t nn = n0 + wn * WTN + j * 32 + M::acc_i(r, lane);
-        if (mm < g.m && nn < g.n) {
-          float* p = c + mm + nn * g.ldc;
-          float out = alpha * acc[i][j][r];
-          if (read_c) {
-            const float bc = beta * (*p);
-            out = out + bc;
-          }
-          *p = out;
-        }
-      }
-    }
-  }
+        return (mm < g.m && nn < g.n) ? c + mm + nn * g.ldc : nullptr;
+      },
+      [&](int i, int j, int r) -> float { return alpha * acc[i][j][r]; }, [](const float* p) -> float { return *p; },
+      [](float* p, float v) { *p = v; });
 }
 
 // ------------------------------------------- batches of one-tile, one-step items
