@@ -642,7 +642,14 @@ struct GemmBody {
       // hides a load that is waited for early, and left to itself the scheduler sinks these loads to the
       // bottom of the step, a few hundred cycles in front of the LDS store that needs them.  Keep them
       // here, a whole K step ahead of that store.
-      if constexpr (K::MI * K::NI == 1) __builtin_amdgcn_sched_barrier(0);
+      // Wavefront tiles of two matrix tiles (fp32 128 x 128 on eight wavefronts) with a K-contiguous operand:
+      // the same sinking (the loads ended up behind the last matrix instructions, a vmcnt(0) at the top of the
+      // next step waiting for them); fenced, NN 2048^3 130 -> 134 TFLOP/s, 4096^3 141.8 -> 143.9, TN 139.0 -> 141.6.
+      // With both operands M/N-contiguous the pattern places them behind the stores by itself (fenced: -1 %).
+      // (Also the 256 x 128 x 32 tile that runs the K slabs of fp32 TN shapes: 8192^3 136.9 -> 140.1 TFLOP/s.  The
+      // 256 x 256 tiles lose 5 % when fenced: there the pattern keeps the loads behind the stores by itself.)
+      constexpr bool SLAB_TN = sizeof(T) == 4 && BM == 256 && BN == 128 && BK == 32 && TA && !TB;
+      if constexpr (K::MI * K::NI == 1 || (K::MI * K::NI == 2 && (TA || !TB)) || SLAB_TN) __builtin_amdgcn_sched_barrier(0);
       pipelined_step<true, NW, NL>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
     }
     if (kt + 1 < nfull) {  // last but one: nothing left to load

@@ -85,6 +85,11 @@ int main(int argc, char** argv) {
     if (run<double, 256, 128, 16, 4, 2, 1, false, false>("f64 256x128x16 NN (4x2 waves)", 8192, 5, 4)) return 1;
   } else if (mode == 'k') {  // K four times as long: what a tile's prologue and epilogue cost
     if (run<float, 256, 256, 16, 2, 4, 2, false, false>("f32 256x256x16 NN (2x4 waves) K x4", 8192, 3, 0, 4)) return 1;
+  } else if (mode == 't') {  // kernels whose compiled K loop has the global loads sunk towards its end
+    if (run<float, 256, 256, 16, 4, 2, 2, true, false>("f32 256x256x16 TN (4x2 waves)", 8192, 10)) return 1;
+    if (run<float, 256, 256, 16, 2, 4, 2, true, true>("f32 256x256x16 TT (2x4 waves)", 8192, 10)) return 1;
+    if (run<float, 256, 128, 32, 4, 2, 1, true, false>("f32 256x128x32 TN (4x2 waves)", 8192, 10)) return 1;
+    if (run<float, 256, 128, 32, 4, 2, 1, true, true>("f32 256x128x32 TT (4x2 waves)", 8192, 10)) return 1;
   } else if (mode == 'l') {
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 4096, 20)) return 1;
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 2048, 100)) return 1;
