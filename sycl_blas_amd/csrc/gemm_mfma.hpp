@@ -351,7 +351,7 @@ struct GemmTile {
   static constexpr size_t LDS_BYTES = 2 * size_t(STAGE_ELEMS) * sizeof(T);
 };
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool FENCE_LOADS = false>
 struct GemmBody {
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
   using M = Mfma<T>;
@@ -649,7 +649,7 @@ struct GemmBody {
       // (Also the 256 x 128 x 32 tile that runs the K slabs of fp32 TN shapes: 8192^3 136.9 -> 140.1 TFLOP/s.  The
       // 256 x 256 tiles lose 5 % when fenced: there the pattern keeps the loads behind the stores by itself.)
       constexpr bool SLAB_TN = sizeof(T) == 4 && BM == 256 && BN == 128 && BK == 32 && TA && !TB;
-      if constexpr (K::MI * K::NI == 1 || (K::MI * K::NI == 2 && (TA || !TB)) || SLAB_TN) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (K::MI * K::NI == 1 || (K::MI * K::NI == 2 && (TA || !TB)) || SLAB_TN || FENCE_LOADS) __builtin_amdgcn_sched_barrier(0);
       pipelined_step<true, NW, NL>(cur, cur + K::A_ELEMS, nxt, nxt + K::A_ELEMS, a_mn, b_mn, lane, fa, fb);
     }
     if (kt + 1 < nfull) {  // last but one: nothing left to load
@@ -1091,7 +1091,9 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
   const int64_t k_begin = int64_t(half) * g.k_chunk;
   const int64_t k_end = k_begin + g.k_chunk;
 
-  GemmBody<T, BM, BN, BK, WM, WN, TA, TB> body;
+  // (fp32 128 x 128 tile, A 'n', B 't': in this kernel hipcc sinks the global loads of the K step behind its last
+  // matrix instructions, which it does not do for the same tile in gemm_mfma_kernel; fenced, +1-2 %)
+  GemmBody<T, BM, BN, BK, WM, WN, TA, TB, (sizeof(T) == 4 && K::MI * K::NI == 2 && !TA && TB)> body;
 #pragma unroll
   for (int i = 0; i < K::MI; ++i)
 #pragma unroll
