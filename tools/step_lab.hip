@@ -90,6 +90,16 @@ int main(int argc, char** argv) {
     if (run<float, 256, 256, 16, 2, 4, 2, true, true>("f32 256x256x16 TT (2x4 waves)", 8192, 10)) return 1;
     if (run<float, 256, 128, 32, 4, 2, 1, true, false>("f32 256x128x32 TN (4x2 waves)", 8192, 10)) return 1;
     if (run<float, 256, 128, 32, 4, 2, 1, true, true>("f32 256x128x32 TT (4x2 waves)", 8192, 10)) return 1;
+  } else if (mode == 's') {  // 64 x 64 tile on fewer, bigger wavefront tiles (the four-wavefront form reads 128 B of LDS per clock when a unit is full)
+    for (int n : {1536, 1024, 3072}) {
+      const int reps = n == 3072 ? 20 : 100;
+      if (run<float, 64, 64, 32, 2, 2, 2, false, false>("f32 64x64x32 NN (4 waves of 32x32)", n, reps)) return 1;
+      if (run<float, 64, 64, 32, 1, 2, 2, false, false>("f32 64x64x32 NN (2 waves of 64x32)", n, reps)) return 1;
+      if (run<float, 64, 64, 32, 2, 1, 2, false, false>("f32 64x64x32 NN (2 waves of 32x64)", n, reps)) return 1;
+      if (run<float, 64, 64, 32, 1, 1, 1, false, false>("f32 64x64x32 NN (1 wave of 64x64)", n, reps)) return 1;
+      if (run<float, 128, 64, 32, 2, 2, 2, false, false>("f32 128x64x32 NN (4 waves of 64x32)", n, reps)) return 1;
+      if (run<float, 64, 128, 32, 2, 2, 2, false, false>("f32 64x128x32 NN (4 waves of 32x64)", n, reps)) return 1;
+    }
   } else if (mode == 'l') {
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 4096, 20)) return 1;
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 2048, 100)) return 1;
