@@ -301,6 +301,7 @@ const char* kernel_name(int k) {
     case SBAMD_KERNEL_INTERLEAVED: return "interleaved";
     case SBAMD_KERNEL_TINY: return "tiny";
     case SBAMD_KERNEL_STREAM: return "stream";
+    case SBAMD_KERNEL_MEDIUM: return "medium";
     default: return "-";
   }
 }
@@ -313,6 +314,7 @@ int kernel_code(const std::string& s) {
   if (s == "splitk") return SBAMD_KERNEL_SPLITK;
   if (s == "naive") return SBAMD_KERNEL_NAIVE;
   if (s == "tiny") return SBAMD_KERNEL_TINY;
+  if (s == "medium") return SBAMD_KERNEL_MEDIUM;
   throw std::runtime_error("unknown --kernel " + s);
 }
 

@@ -78,6 +78,7 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     cands.push_back({"interleaved 4x4 register tile", SBAMD_KERNEL_INTERLEAVED, 0, true});
   } else {
     cands.push_back({sizeof(T) == 4 ? "huge   256x256 tile, 8 waves" : "huge   256x128 tile, 8 waves", SBAMD_KERNEL_HUGE, 0, true});
+    if (sizeof(T) == 4) cands.push_back({"medium  96x96  tile, 4 waves (16x16x4 instruction)", SBAMD_KERNEL_MEDIUM, 0, true});
     cands.push_back({sizeof(T) == 4 ? "large  128x128 tile, 8 waves" : "large  128x128 tile, 4 waves", SBAMD_KERNEL_LARGE, 0, true});
     cands.push_back({"small   64x64  tile, 4 waves", SBAMD_KERNEL_SMALL, 0, true});
     cands.push_back({"small   64x64  tile, register-staged only", SBAMD_KERNEL_SMALL, 1, true});
@@ -121,9 +122,9 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
       if (cand.kernel == SBAMD_KERNEL_AUTO) {
         int64_t depth = 1, chunk = 0;
         sbamd_last_splitk(h, &depth, &chunk);
-        static const char* names[] = {"auto", "large", "small", "splitk", "naive", "huge", "interleaved", "tiny"};
+        static const char* names[] = {"auto", "large", "small", "splitk", "naive", "huge", "interleaved", "tiny", "stream", "medium"};
         const int picked = sbamd_last_kernel(h);
-        o.note = std::string("-> ") + (picked >= 0 && picked <= 7 ? names[picked] : "?");
+        o.note = std::string("-> ") + (picked >= 0 && picked <= 9 ? names[picked] : "?");
         if (depth > 1) o.note += " depth " + std::to_string(depth);
         o.cand.exact = depth <= 1;
       }

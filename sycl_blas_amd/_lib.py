@@ -24,6 +24,7 @@ KERNEL_AUTO, KERNEL_LARGE, KERNEL_SMALL, KERNEL_SPLITK, KERNEL_NAIVE, KERNEL_HUG
 KERNEL_INTERLEAVED = 6
 KERNEL_TINY = 7
 KERNEL_STREAM = 8
+KERNEL_MEDIUM = 9
 
 _i64, _int, _f32, _f64, _vp, _ch = C.c_int64, C.c_int, C.c_float, C.c_double, C.c_void_p, C.c_char
 

@@ -37,10 +37,10 @@ inline int group_m_override() {
   return value;
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB, typename MS = Mfma<T>>
 hipError_t launch_one(const GemmArgs<T>& g, int64_t nz, hipStream_t stream) {
-  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
-  auto kernel = gemm_mfma_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC>;
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB, MS>;
+  auto kernel = gemm_mfma_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC, MS>;
   static PerDeviceOnce lds_limit;
   hipError_t e = lds_limit.run([&] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -57,17 +57,17 @@ hipError_t launch_one(const GemmArgs<T>& g, int64_t nz, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC = 1>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC = 1, typename MS = Mfma<T>>
 hipError_t launch_tile(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
   g.tiles_m = int32_t(ceil_div(g.m, BM));
   g.tiles_n = int32_t(ceil_div(g.n, BN));
   const int64_t nz = g.split_k > 1 ? g.split_k : g.batch;
   if (ta) {
-    return tb ? launch_one<T, BM, BN, BK, WM, WN, OCC, true, true>(g, nz, stream)
-              : launch_one<T, BM, BN, BK, WM, WN, OCC, true, false>(g, nz, stream);
+    return tb ? launch_one<T, BM, BN, BK, WM, WN, OCC, true, true, MS>(g, nz, stream)
+              : launch_one<T, BM, BN, BK, WM, WN, OCC, true, false, MS>(g, nz, stream);
   }
-  return tb ? launch_one<T, BM, BN, BK, WM, WN, OCC, false, true>(g, nz, stream)
-            : launch_one<T, BM, BN, BK, WM, WN, OCC, false, false>(g, nz, stream);
+  return tb ? launch_one<T, BM, BN, BK, WM, WN, OCC, false, true, MS>(g, nz, stream)
+            : launch_one<T, BM, BN, BK, WM, WN, OCC, false, false, MS>(g, nz, stream);
 }
 
 // fp32 tiles staged global -> LDS directly (gemm_mfma_dma_kernel): K in whole K steps, both operands
@@ -287,7 +287,7 @@ struct Tiles<double> {
 };
 
 // What to launch: a tile shape and how many K slabs (1 = a single kernel).
-enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5 };
+enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5, TILE_96 = 6 };  // TILE_96: float only, single launches only
 struct Plan {
   int tile;
   int64_t depth;
@@ -317,6 +317,9 @@ struct CostModel<float> {
   static constexpr double small_k[4] = {0.0181, 0.0372, 0.0555, 0.0726};
   static constexpr double large_k[2] = {0.0700, 0.1223};  // one per unit: 0.0695-0.0754 measured with every unit busy (the fit, pulled down by launches that leave units idle, said 0.0617)
   static constexpr double huge_k[1] = {0.2416};  // 256 x 256 tile
+  // 96 x 96 tile on the 16x16x4 instruction, one / two workgroups per unit (1536^3, 256 tiles: 64.5 us; 3072^3,
+  // 1024 tiles: 454 us; tools/step_lab.hip m)
+  static constexpr double medium_k[2] = {0.0394, 0.0732};
   // two K halves in one workgroup, relative to two resident workgroups of the tile {64x64, 128x128}
   // (medians over the sweep's shapes that leave at least half of a unit's workgroup slots empty)
   static constexpr double halves_factor[2] = {0.903, 0.986};
@@ -328,6 +331,7 @@ struct CostModel<double> {
   static constexpr double small_k[4] = {0.0380, 0.0785, 0.1027, 0.1300};
   static constexpr double large_k[2] = {0.1205, 0.2393};
   static constexpr double huge_k[1] = {0.2346};
+  static constexpr double medium_k[2] = {1e3, 1e3};  // no such tile for double
   static constexpr double halves_factor[2] = {0.807, 0.967};
   static constexpr CostOverheads over = {5.12, 7.20, 5.83e6, 0.0397};
 };
@@ -362,11 +366,11 @@ template <typename T>
 inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t k, int64_t batch, int cus,
                           bool fused = false) {
   using C = CostModel<T>;
-  const int bm = tile == TILE_256 ? 256 : tile == TILE_128 ? 128 : 64;
-  const int bn = tile == TILE_64 ? 64 : tile == TILE_128 ? 128 : Tiles<T>::HUGE_BN;
-  const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
-  const int occ = tile == TILE_256 ? 1 : tile == TILE_128 ? 2 : 4;
-  const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : C::small_k;
+  const int bm = tile == TILE_256 ? 256 : tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : 64;
+  const int bn = tile == TILE_64 ? 64 : tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : Tiles<T>::HUGE_BN;
+  const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : tile == TILE_96 ? 32 : Tiles<T>::SMALL_BK;
+  const int occ = tile == TILE_256 ? 1 : (tile == TILE_128 || tile == TILE_96) ? 2 : 4;
+  const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : tile == TILE_96 ? C::medium_k : C::small_k;
   const int64_t wgs = ceil_div(m, bm) * ceil_div(n, bn) * batch * depth;
   // workgroups the fullest compute unit runs; the sets of a fused workgroup always share a unit
   const int64_t busiest = fused ? ceil_div(wgs / depth, cus) * depth : ceil_div(wgs, cus);
@@ -399,6 +403,13 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
   for (int tile = TILE_64; tile <= TILE_256; ++tile) {
     const double us = estimate_us<T>(tile, 1, m, n, k, batch, cus);
     if (us < best_us) best_us = us, best = {tile, 1};
+  }
+  // The 96 x 96 tile (float): where the other tile counts quantise badly over the units (1536^3: 576 tiles of
+  // 64 x 64 are three on the busiest unit, 256 tiles of 96 x 96 one each: 84 -> 65 us).  Its two constants come
+  // from two shapes, so it has to win by 3 %.
+  if constexpr (sizeof(T) == 4) {
+    const double us = 1.03 * estimate_us<T>(TILE_96, 1, m, n, k, batch, cus);
+    if (us < best_us) best_us = us, best = {TILE_96, 1};
   }
   if (batch != 1) return best;
   // Cutting K (the reference does it for its tall-skinny class only,
@@ -538,6 +549,9 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     case SBAMD_KERNEL_SMALL: plan = {TILE_64, 1}; break;
     case SBAMD_KERNEL_TINY: plan = {TILE_32, 1}; break;
     case SBAMD_KERNEL_NAIVE: plan = {TILE_NAIVE, 1}; break;
+    case SBAMD_KERNEL_MEDIUM:
+      if (sizeof(T) == 4) plan = {TILE_96, 1};
+      break;
     case SBAMD_KERNEL_SPLITK:
       if (pin_tile >= TILE_64 && pin_tile <= TILE_256) plan.tile = pin_tile;
       else if (plan.tile > TILE_256) plan.tile = TILE_64;
@@ -559,6 +573,14 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   if (plan.tile == TILE_32) {
     h->last_kernel = SBAMD_KERNEL_TINY;
     return launch_tile<T, 32, 32, Tiles<T>::TINY_BK, 1, 1, 4>(g, p.ta, p.tb, h->stream);
+  }
+  if (plan.tile == TILE_96) {
+    if constexpr (sizeof(T) == 4) {
+      h->last_kernel = SBAMD_KERNEL_MEDIUM;
+      return launch_tile<T, 96, 96, 32, 2, 2, 2, MfmaF32Small>(g, p.ta, p.tb, h->stream);
+    } else {
+      plan.tile = TILE_64;
+    }
   }
 
   const int bk = plan.tile == TILE_256 ? Tiles<T>::HUGE_BK : plan.tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;

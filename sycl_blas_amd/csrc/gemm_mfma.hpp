@@ -119,6 +119,29 @@ struct Mfma<double> {
   static constexpr int PAD_MN = 16;
 };
 
+// v_mfma_f32_16x16x4_f32 (the small fp32 shape, for tiles that are multiples of 48): lane l feeds
+// op0[i = l & 15][k = l >> 4] and op1[k = l >> 4][j = l & 15]; it receives D[i][j = l & 15] for
+// i = 4 * (l >> 4) + r, r = 0..3.  Its four products are added in k order, each a fused multiply-add
+// (tools/mfma16_order.hip: 256 of 256 elements of a K = 64 product equal the fmaf chain), so a kernel built on
+// it produces the same bits as one built on 32x32x2.
+struct MfmaF32Small {
+  static constexpr int T = 16;
+  static constexpr int TK = 4;
+  static constexpr int NACC = 4;
+  using acc_t = f32x4;
+  using vec_t = f32x4;
+  static constexpr int V = 4;
+  __device__ static inline acc_t mma(float op0, float op1, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(op0, op1, c, 0, 0, 0);
+  }
+  __device__ static inline int lane_mn(int lane) { return lane & 15; }
+  __device__ static inline int lane_k(int lane) { return lane >> 4; }
+  __device__ static inline int acc_i(int r, int lane) { return 4 * (lane >> 4) + r; }
+  static constexpr int GS = 1;
+  // [k][mn] image: a row stride of 16 (mod 32) floats puts the lanes of k and k + 1 on the two halves of the banks
+  static constexpr int PAD_MN = 16;
+};
+
 // ------------------------------------------------------------- tile loading
 //
 // An operand tile covers BMN indices along M (or N) and BK along K.
@@ -135,9 +158,9 @@ struct Mfma<double> {
 //     read over all banks.  For fp32 every aligned group of four k is stored
 //     as (k0, k2, k1, k3), so lane-half h reads the 8 bytes (k = 4j + h,
 //     k = 4j + 2 + h): exactly its operands for MFMA steps 2j and 2j + 1.
-template <typename T, int BMN, int BK, int NT, bool KMAJOR>
+template <typename T, int BMN, int BK, int NT, bool KMAJOR, typename MS = Mfma<T>>
 struct TileLoader {
-  using M = Mfma<T>;
+  using M = MS;
   static constexpr int V = M::V;
   static constexpr int S = KMAJOR ? (BK + 2) : (BMN + M::PAD_MN);  // LDS row stride (elements)
   static constexpr int ELEMS = KMAJOR ? BMN * S : BK * S;
@@ -146,7 +169,7 @@ struct TileLoader {
   static_assert(BK % 4 == 0, "K step is handled in groups of four");
   static constexpr int NV = NVEC / NT;
   static constexpr int PER_ROW = KMAJOR ? (BK / V) : (BMN / V);
-  static constexpr int NWRITE = NV * ((KMAJOR && V == 4) ? 2 : 1);  // LDS store instructions per tile
+  static constexpr int NWRITE = NV * ((KMAJOR && M::GS == 2) ? 2 : 1);  // LDS store instructions per tile
 
   T reg[NV][V];
   // Global memory takes a 16-byte load at element alignment; this type tells the compiler so.
@@ -261,7 +284,7 @@ struct TileLoader {
       const int row = v / PER_ROW;
       const int col = (v % PER_ROW) * V;
       SBAMD_LDS T* p = lds + row * S + col;
-      if (KMAJOR && V == 4) {
+      if (KMAJOR && M::GS == 2) {
         // (k0, k2, k1, k3), written element by element.  (Built from 8-byte vector stores, the register
         // pairs (k0, k2) / (k1, k3) have to be assembled first, and hipcc assembles them right behind the
         // global loads at the bottom of the K loop -- waiting there for loads it has just issued, every
@@ -331,9 +354,9 @@ __device__ inline void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int
 }
 
 // ------------------------------------------------------------------ the kernel
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, typename MS = Mfma<T>>
 struct GemmTile {
-  using M = Mfma<T>;
+  using M = MS;
   static constexpr int NT = WM * WN * 64;
   static constexpr int WTM = BM / WM;  // wavefront tile
   static constexpr int WTN = BN / WN;
@@ -343,18 +366,18 @@ struct GemmTile {
   static constexpr int NGRP = BK / (M::TK * M::GS);
   static_assert(BK % (M::TK * M::GS) == 0, "BK must hold whole fragment groups");
   // A is K-major when transposed; B is K-major when NOT transposed.
-  using LoadA = TileLoader<T, BM, BK, NT, TA>;
-  using LoadB = TileLoader<T, BN, BK, NT, !TB>;
+  using LoadA = TileLoader<T, BM, BK, NT, TA, MS>;
+  using LoadB = TileLoader<T, BN, BK, NT, !TB, MS>;
   static constexpr int A_ELEMS = (LoadA::ELEMS + 3) & ~3;  // keep B 16-byte aligned
   static constexpr int B_ELEMS = (LoadB::ELEMS + 3) & ~3;
   static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
   static constexpr size_t LDS_BYTES = 2 * size_t(STAGE_ELEMS) * sizeof(T);
 };
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool FENCE_LOADS = false>
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, bool FENCE_LOADS = false, typename MS = Mfma<T>>
 struct GemmBody {
-  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
-  using M = Mfma<T>;
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB, MS>;
+  using M = MS;
   using LoadA = typename K::LoadA;
   using LoadB = typename K::LoadB;
 
@@ -468,7 +491,7 @@ struct GemmBody {
     // 256 x 256 tile 145.4 -> 146.5-146.8 TFLOP/s; the 128 x 128 tile on eight wavefronts measured no gain and keeps
     // the caller's count).
     constexpr int NWR = (NWRITE > 0 && K::MI * K::NI >= 4)
-                            ? LoadA::NV * ((TA && M::V == 4) ? 4 : 1) + LoadB::NV * ((!TB && M::V == 4) ? 4 : 1)
+                            ? LoadA::NV * ((TA && M::GS == 2) ? 4 : 1) + LoadB::NV * ((!TB && M::GS == 2) ? 4 : 1)
                             : NWRITE;
 #pragma unroll
     for (int n = 0; n < (K::NGRP - 1) * NM; ++n) {
@@ -909,7 +932,8 @@ __device__ inline void store_tiles_interior(bool read_c, V beta, TMem* origin, i
   static_assert(sizeof(TMem) == sizeof(V) || (sizeof(TMem) == 2 && sizeof(V) == 4), "same type, or halves behind floats");
   static_assert(sizeof(V) == 4 || sizeof(V) == 8, "4- or 8-byte arithmetic");
   constexpr int E = MI * NI * NACC;
-  constexpr int B = sizeof(V) == 4 ? 16 : 8;  // elements per batch
+  // elements per batch: 16 four-byte or 8 eight-byte loads in flight, less where the tile does not divide that way
+  constexpr int B = sizeof(V) == 4 ? (E % 16 == 0 ? 16 : E % 12 == 0 ? 12 : E % 8 == 0 ? 8 : 4) : (E % 8 == 0 ? 8 : 4);
   static_assert(E % B == 0, "whole batches");
   // (readfirstlane returns a signed int: widen through uint32_t, or a low half with its top bit set smears
   // ones over the high half)
@@ -967,11 +991,11 @@ __device__ inline void store_tiles_interior(bool read_c, V beta, TMem* origin, i
 }
 
 // OCC = waves per SIMD the register allocation must leave room for.
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC>
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC, typename MS = Mfma<T>>
 __global__ void __launch_bounds__(WM* WN * 64, OCC)
     gemm_mfma_kernel(const GemmArgs<T> g) {
-  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
-  using M = Mfma<T>;
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB, MS>;
+  using M = MS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SBAMD_LDS T* smem = (SBAMD_LDS T*)smem_raw;
 
@@ -1004,7 +1028,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     c += int64_t(z) * g.stride_c;
   }
 
-  GemmBody<T, BM, BN, BK, WM, WN, TA, TB> body;
+  GemmBody<T, BM, BN, BK, WM, WN, TA, TB, false, MS> body;
 #pragma unroll
   for (int i = 0; i < K::MI; ++i)
 #pragma unroll

@@ -381,7 +381,8 @@ const char* sbamd_last_error(sbamd_handle_t h) { return h ? h->impl.last_error.c
 
 int sbamd_set_kernel(sbamd_handle_t h, int kernel, int param) {
   if (!h) return SBAMD_INVALID_HANDLE;
-  if (kernel < SBAMD_KERNEL_AUTO || kernel > SBAMD_KERNEL_TINY || kernel == SBAMD_KERNEL_INTERLEAVED || param < 0)
+  if (kernel < SBAMD_KERNEL_AUTO || (kernel > SBAMD_KERNEL_TINY && kernel != SBAMD_KERNEL_MEDIUM) || kernel == SBAMD_KERNEL_INTERLEAVED ||
+      param < 0)
     return SBAMD_INVALID_VALUE;
   h->impl.kernel_override = kernel;
   h->impl.kernel_param = param;

@@ -20,9 +20,9 @@ using namespace sbamd;
     }                                                                         \
   } while (0)
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB, typename MS = Mfma<T>>
 int run(const char* name, int n, int reps, int group_m = 0, int kmul = 1) {
-  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB, MS>;
   T *a, *b, *c;
   CHECK(hipMalloc(&a, sizeof(T) * n * n * kmul));
   CHECK(hipMalloc(&b, sizeof(T) * n * n * kmul));
@@ -44,7 +44,7 @@ int run(const char* name, int n, int reps, int group_m = 0, int kmul = 1) {
   g.vec_a = g.vec_b = 1;
   g.alpha = T(1); g.beta = T(0); g.beta_zero = 1;
   g.group_m = group_m;
-  auto kernel = gemm_mfma_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC>;
+  auto kernel = gemm_mfma_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC, MS>;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             int(K::LDS_BYTES)));
   hipEvent_t e0, e1;
@@ -99,6 +99,16 @@ int main(int argc, char** argv) {
       if (run<float, 64, 64, 32, 1, 1, 1, false, false>("f32 64x64x32 NN (1 wave of 64x64)", n, reps)) return 1;
       if (run<float, 128, 64, 32, 2, 2, 2, false, false>("f32 128x64x32 NN (4 waves of 64x32)", n, reps)) return 1;
       if (run<float, 64, 128, 32, 2, 2, 2, false, false>("f32 64x128x32 NN (4 waves of 32x64)", n, reps)) return 1;
+    }
+  } else if (mode == 'm') {  // 96 x 96 tile on the 16x16x4 instruction against the 64 x 64 and 128 x 128 tiles
+    for (int n : {1536, 3072}) {
+      const int reps = n == 3072 ? 20 : 100;
+      if (run<float, 64, 64, 32, 2, 2, 2, false, false>("f32 64x64x32 NN (4 waves of 32x32)", n, reps)) return 1;
+      if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", n, reps)) return 1;
+      if (run<float, 96, 96, 32, 2, 2, 1, false, false, MfmaF32Small>("f32 96x96x32 NN (4 waves of 48x48, 16x16x4) occ1", n, reps)) return 1;
+      if (run<float, 96, 96, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 96x96x32 NN (4 waves of 48x48, 16x16x4) occ2", n, reps)) return 1;
+      if (run<float, 96, 96, 32, 2, 2, 2, true, false, MfmaF32Small>("f32 96x96x32 TN (16x16x4) occ2", n, reps)) return 1;
+      if (run<float, 96, 96, 32, 2, 2, 2, false, true, MfmaF32Small>("f32 96x96x32 NT (16x16x4) occ2", n, reps)) return 1;
     }
   } else if (mode == 'l') {
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 4096, 20)) return 1;
