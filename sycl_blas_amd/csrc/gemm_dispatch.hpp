@@ -287,7 +287,7 @@ struct Tiles<double> {
 };
 
 // What to launch: a tile shape and how many K slabs (1 = a single kernel).
-enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5, TILE_96 = 6 };  // TILE_96: float only, single launches only
+enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5, TILE_96 = 6, TILE_192 = 7 };  // TILE_96 / TILE_192: float only, single launches only
 struct Plan {
   int tile;
   int64_t depth;
@@ -320,6 +320,8 @@ struct CostModel<float> {
   // 96 x 96 tile on the 16x16x4 instruction, one / two workgroups per unit (1536^3, 256 tiles: 64.5 us; 3072^3,
   // 1024 tiles: 454 us; tools/step_lab.hip m)
   static constexpr double medium_k[2] = {0.0394, 0.0732};
+  // 192 x 192 tile on the same instruction, eight wavefronts of 96 x 48, one workgroup per unit (3072^3, 256 tiles: 415 us)
+  static constexpr double wide_k[1] = {0.1340};
   // two K halves in one workgroup, relative to two resident workgroups of the tile {64x64, 128x128}
   // (medians over the sweep's shapes that leave at least half of a unit's workgroup slots empty)
   static constexpr double halves_factor[2] = {0.903, 0.986};
@@ -331,7 +333,8 @@ struct CostModel<double> {
   static constexpr double small_k[4] = {0.0380, 0.0785, 0.1027, 0.1300};
   static constexpr double large_k[2] = {0.1205, 0.2393};
   static constexpr double huge_k[1] = {0.2346};
-  static constexpr double medium_k[2] = {1e3, 1e3};  // no such tile for double
+  static constexpr double medium_k[2] = {1e3, 1e3};  // no such tiles for double
+  static constexpr double wide_k[1] = {1e3};
   static constexpr double halves_factor[2] = {0.807, 0.967};
   static constexpr CostOverheads over = {5.12, 7.20, 5.83e6, 0.0397};
 };
@@ -366,11 +369,11 @@ template <typename T>
 inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t k, int64_t batch, int cus,
                           bool fused = false) {
   using C = CostModel<T>;
-  const int bm = tile == TILE_256 ? 256 : tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : 64;
-  const int bn = tile == TILE_64 ? 64 : tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : Tiles<T>::HUGE_BN;
-  const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : tile == TILE_96 ? 32 : Tiles<T>::SMALL_BK;
-  const int occ = tile == TILE_256 ? 1 : (tile == TILE_128 || tile == TILE_96) ? 2 : 4;
-  const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : tile == TILE_96 ? C::medium_k : C::small_k;
+  const int bm = tile == TILE_256 ? 256 : tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : tile == TILE_192 ? 192 : 64;
+  const int bn = tile == TILE_64 ? 64 : tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : tile == TILE_192 ? 192 : Tiles<T>::HUGE_BN;
+  const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : (tile == TILE_96 || tile == TILE_192) ? 32 : Tiles<T>::SMALL_BK;
+  const int occ = (tile == TILE_256 || tile == TILE_192) ? 1 : (tile == TILE_128 || tile == TILE_96) ? 2 : 4;
+  const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : tile == TILE_96 ? C::medium_k : tile == TILE_192 ? C::wide_k : C::small_k;
   const int64_t wgs = ceil_div(m, bm) * ceil_div(n, bn) * batch * depth;
   // workgroups the fullest compute unit runs; the sets of a fused workgroup always share a unit
   const int64_t busiest = fused ? ceil_div(wgs / depth, cus) * depth : ceil_div(wgs, cus);
@@ -408,8 +411,10 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
   // 64 x 64 are three on the busiest unit, 256 tiles of 96 x 96 one each: 84 -> 65 us).  Its two constants come
   // from two shapes, so it has to win by 3 %.
   if constexpr (sizeof(T) == 4) {
-    const double us = 1.03 * estimate_us<T>(TILE_96, 1, m, n, k, batch, cus);
-    if (us < best_us) best_us = us, best = {TILE_96, 1};
+    for (int tile : {TILE_96, TILE_192}) {
+      const double us = 1.03 * estimate_us<T>(tile, 1, m, n, k, batch, cus);
+      if (us < best_us) best_us = us, best = {tile, 1};
+    }
   }
   if (batch != 1) return best;
   // Cutting K (the reference does it for its tall-skinny class only,
@@ -549,8 +554,8 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     case SBAMD_KERNEL_SMALL: plan = {TILE_64, 1}; break;
     case SBAMD_KERNEL_TINY: plan = {TILE_32, 1}; break;
     case SBAMD_KERNEL_NAIVE: plan = {TILE_NAIVE, 1}; break;
-    case SBAMD_KERNEL_MEDIUM:
-      if (sizeof(T) == 4) plan = {TILE_96, 1};
+    case SBAMD_KERNEL_MEDIUM:  // parameter bit 0: the 192 x 192 tile
+      if (sizeof(T) == 4) plan = {(h->kernel_param & 1) ? TILE_192 : TILE_96, 1};
       break;
     case SBAMD_KERNEL_SPLITK:
       if (pin_tile >= TILE_64 && pin_tile <= TILE_256) plan.tile = pin_tile;
@@ -574,9 +579,10 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     h->last_kernel = SBAMD_KERNEL_TINY;
     return launch_tile<T, 32, 32, Tiles<T>::TINY_BK, 1, 1, 4>(g, p.ta, p.tb, h->stream);
   }
-  if (plan.tile == TILE_96) {
+  if (plan.tile == TILE_96 || plan.tile == TILE_192) {
     if constexpr (sizeof(T) == 4) {
       h->last_kernel = SBAMD_KERNEL_MEDIUM;
+      if (plan.tile == TILE_192) return launch_tile<T, 192, 192, 32, 2, 4, 2, MfmaF32Small>(g, p.ta, p.tb, h->stream);
       return launch_tile<T, 96, 96, 32, 2, 2, 2, MfmaF32Small>(g, p.ta, p.tb, h->stream);
     } else {
       plan.tile = TILE_64;

@@ -110,6 +110,28 @@ int main(int argc, char** argv) {
       if (run<float, 96, 96, 32, 2, 2, 2, true, false, MfmaF32Small>("f32 96x96x32 TN (16x16x4) occ2", n, reps)) return 1;
       if (run<float, 96, 96, 32, 2, 2, 2, false, true, MfmaF32Small>("f32 96x96x32 NT (16x16x4) occ2", n, reps)) return 1;
     }
+  } else if (mode == 'n') {  // the 16x16x4 instruction on the other tile sizes (more independent accumulators per wavefront)
+    if (run<float, 64, 64, 32, 2, 2, 2, false, false>("f32 64x64x32 NN (32x32x2, far pipeline)", 1024, 200)) return 1;
+    if (run<float, 64, 64, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 64x64x32 NN (16x16x4, 4 waves of 32x32)", 1024, 200)) return 1;
+    if (run<float, 64, 64, 64, 2, 2, 2, false, false, MfmaF32Small>("f32 64x64x64 NN (16x16x4, 4 waves of 32x32)", 1024, 200)) return 1;
+    if (run<float, 64, 64, 32, 2, 2, 2, false, true, MfmaF32Small>("f32 64x64x32 NT (16x16x4, 4 waves of 32x32)", 1024, 200)) return 1;
+    if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (32x32x2, 8 waves of 32x64)", 2048, 100)) return 1;
+    if (run<float, 128, 128, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 128x128x32 NN (16x16x4, 4 waves of 64x64)", 2048, 100)) return 1;
+    if (run<float, 128, 128, 32, 4, 2, 2, false, false, MfmaF32Small>("f32 128x128x32 NN (16x16x4, 8 waves of 32x64)", 2048, 100)) return 1;
+    if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (32x32x2, 8 waves of 32x64)", 4096, 20)) return 1;
+    if (run<float, 128, 128, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 128x128x32 NN (16x16x4, 4 waves of 64x64)", 4096, 20)) return 1;
+    if (run<float, 128, 128, 32, 4, 2, 2, false, false, MfmaF32Small>("f32 128x128x32 NN (16x16x4, 8 waves of 32x64)", 4096, 20)) return 1;
+    if (run<float, 96, 96, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 96x96x32 NN (16x16x4)", 768, 200)) return 1;
+    if (run<float, 64, 64, 32, 2, 2, 2, false, false>("f32 64x64x32 NN (32x32x2, far pipeline)", 768, 200)) return 1;
+    if (run<float, 64, 64, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 64x64x32 NN (16x16x4)", 768, 200)) return 1;
+  } else if (mode == 'b') {  // 192 x 192 on the 16x16x4 instruction: 256 tiles at 3072^3
+    if (run<float, 96, 96, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 96x96x32 NN (16x16x4)", 3072, 20)) return 1;
+    if (run<float, 192, 192, 32, 2, 4, 2, false, false, MfmaF32Small>("f32 192x192x32 NN (16x16x4, 8 waves of 96x48)", 3072, 20)) return 1;
+    if (run<float, 192, 192, 32, 4, 2, 2, false, false, MfmaF32Small>("f32 192x192x32 NN (16x16x4, 8 waves of 48x96)", 3072, 20)) return 1;
+    if (run<float, 192, 192, 32, 2, 2, 1, false, false, MfmaF32Small>("f32 192x192x32 NN (16x16x4, 4 waves of 96x96)", 3072, 20)) return 1;
+    if (run<float, 192, 192, 32, 2, 4, 2, false, true, MfmaF32Small>("f32 192x192x32 NT (16x16x4, 8 waves of 96x48)", 3072, 20)) return 1;
+    if (run<float, 192, 192, 32, 2, 4, 2, true, false, MfmaF32Small>("f32 192x192x32 TN (16x16x4, 8 waves of 96x48)", 3072, 20)) return 1;
+    if (run<float, 192, 96, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 192x96x32 NN (16x16x4, 4 waves of 96x48)", 3072, 20)) return 1;
   } else if (mode == 'l') {
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 4096, 20)) return 1;
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 2048, 100)) return 1;
