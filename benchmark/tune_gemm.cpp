@@ -78,8 +78,8 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     cands.push_back({"interleaved 4x4 register tile", SBAMD_KERNEL_INTERLEAVED, 0, true});
   } else {
     cands.push_back({sizeof(T) == 4 ? "huge   256x256 tile, 8 waves" : "huge   256x128 tile, 8 waves", SBAMD_KERNEL_HUGE, 0, true});
-    if (sizeof(T) == 4) cands.push_back({"medium  96x96  tile, 4 waves (16x16x4 instruction)", SBAMD_KERNEL_MEDIUM, 0, true});
-    if (sizeof(T) == 4) cands.push_back({"medium 192x192 tile, 8 waves (16x16x4 instruction)", SBAMD_KERNEL_MEDIUM, 1, true});
+    cands.push_back({"medium  96x96  tile, 4 waves (16x16x4 instruction)", SBAMD_KERNEL_MEDIUM, 0, true});
+    cands.push_back({"medium 192x192 tile, 8 waves (16x16x4 instruction)", SBAMD_KERNEL_MEDIUM, 1, true});
     cands.push_back({sizeof(T) == 4 ? "large  128x128 tile, 8 waves" : "large  128x128 tile, 4 waves", SBAMD_KERNEL_LARGE, 0, true});
     cands.push_back({"small   64x64  tile, 4 waves", SBAMD_KERNEL_SMALL, 0, true});
     cands.push_back({"small   64x64  tile, register-staged only", SBAMD_KERNEL_SMALL, 1, true});

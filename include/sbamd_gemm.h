@@ -71,7 +71,7 @@ enum {
   SBAMD_KERNEL_INTERLEAVED = 6, /* batch-contiguous layout; reported, not pinnable */
   SBAMD_KERNEL_TINY = 7,     /* 32x32 macro tile, one wavefront (batches of small matrices) */
   SBAMD_KERNEL_STREAM = 8,   /* long batches of 64x64x64-class items, or the 64x64 tiles of one product with K = 64, on resident workgroups; reported, not pinnable */
-  SBAMD_KERNEL_MEDIUM = 9    /* 96x96 macro tile (parameter bit 0: 192x192) on the 16x16x4 matrix instruction (float; double and the 16-bit pairs choose by themselves when it is pinned) */
+  SBAMD_KERNEL_MEDIUM = 9    /* 96x96 macro tile (parameter bit 0: 192x192) on the 16x16x4 matrix instructions (float, double; the 16-bit pairs choose by themselves when it is pinned) */
 };
 
 typedef struct sbamd_handle_s* sbamd_handle_t;

@@ -278,16 +278,20 @@ struct Tiles<float> {
   static constexpr int LARGE_BK = 32, SMALL_BK = 32, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 256, HUGE_OCC = 2, TINY_BK = 16, STREAM_OCC = 4;
   static constexpr int LARGE_WM = 4;  // 128 x 128 as eight waves of 32 x 64: 4-6 % faster than four of 64 x 64 at 2048^3..4096^3
   static constexpr int SMALL_OCC = 2;
+  static constexpr int MEDIUM_BK = 32;  // the 96 x 96 and 192 x 192 tiles, on the 16x16x4 instruction
+  using MediumShape = MfmaF32Small;
 };
 template <>
 struct Tiles<double> {
   static constexpr int LARGE_BK = 16, SMALL_BK = 16, HUGE_BK = 16, ONESHOT_BK = 64, HUGE_BN = 128, HUGE_OCC = 1, TINY_BK = 8, STREAM_OCC = 2;
   static constexpr int LARGE_WM = 2;  // four waves of 64 x 64 (eight waves gain nothing in fp64)
   static constexpr int SMALL_OCC = 2;
+  static constexpr int MEDIUM_BK = 16;
+  using MediumShape = Mfma<double>;
 };
 
 // What to launch: a tile shape and how many K slabs (1 = a single kernel).
-enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5, TILE_96 = 6, TILE_192 = 7 };  // TILE_96 / TILE_192: float only, single launches only
+enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5, TILE_96 = 6, TILE_192 = 7 };  // TILE_96 / TILE_192: single launches only
 struct Plan {
   int tile;
   int64_t depth;
@@ -333,8 +337,9 @@ struct CostModel<double> {
   static constexpr double small_k[4] = {0.0380, 0.0785, 0.1027, 0.1300};
   static constexpr double large_k[2] = {0.1205, 0.2393};
   static constexpr double huge_k[1] = {0.2346};
-  static constexpr double medium_k[2] = {1e3, 1e3};  // no such tiles for double
-  static constexpr double wide_k[1] = {1e3};
+  // 96 x 96 (1536^3: 112 us against 149 on 64 x 64; 3072^3: 822 us) and 192 x 192 (3072^3: 805 us), tools/step_lab.hip d
+  static constexpr double medium_k[2] = {0.0697, 0.1330};
+  static constexpr double wide_k[1] = {0.2604};
   static constexpr double halves_factor[2] = {0.807, 0.967};
   static constexpr CostOverheads over = {5.12, 7.20, 5.83e6, 0.0397};
 };
@@ -371,7 +376,7 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
   using C = CostModel<T>;
   const int bm = tile == TILE_256 ? 256 : tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : tile == TILE_192 ? 192 : 64;
   const int bn = tile == TILE_64 ? 64 : tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : tile == TILE_192 ? 192 : Tiles<T>::HUGE_BN;
-  const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : (tile == TILE_96 || tile == TILE_192) ? 32 : Tiles<T>::SMALL_BK;
+  const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : (tile == TILE_96 || tile == TILE_192) ? Tiles<T>::MEDIUM_BK : Tiles<T>::SMALL_BK;
   const int occ = (tile == TILE_256 || tile == TILE_192) ? 1 : (tile == TILE_128 || tile == TILE_96) ? 2 : 4;
   const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : tile == TILE_96 ? C::medium_k : tile == TILE_192 ? C::wide_k : C::small_k;
   const int64_t wgs = ceil_div(m, bm) * ceil_div(n, bn) * batch * depth;
@@ -407,14 +412,12 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
     const double us = estimate_us<T>(tile, 1, m, n, k, batch, cus);
     if (us < best_us) best_us = us, best = {tile, 1};
   }
-  // The 96 x 96 tile (float): where the other tile counts quantise badly over the units (1536^3: 576 tiles of
-  // 64 x 64 are three on the busiest unit, 256 tiles of 96 x 96 one each: 84 -> 65 us).  Its two constants come
-  // from two shapes, so it has to win by 3 %.
-  if constexpr (sizeof(T) == 4) {
-    for (int tile : {TILE_96, TILE_192}) {
-      const double us = 1.03 * estimate_us<T>(tile, 1, m, n, k, batch, cus);
-      if (us < best_us) best_us = us, best = {tile, 1};
-    }
+  // The 96 x 96 and 192 x 192 tiles: where the other tile counts quantise badly over the units (fp32 1536^3: 576
+  // tiles of 64 x 64 are three on the busiest unit, 256 tiles of 96 x 96 one each: 84 -> 65 us; 3072^3: 256 tiles
+  // of 192 x 192, 489 -> 415 us).  Their constants come from two shapes each, so they have to win by 6 %.
+  for (int tile : {TILE_96, TILE_192}) {
+    const double us = 1.06 * estimate_us<T>(tile, 1, m, n, k, batch, cus);
+    if (us < best_us) best_us = us, best = {tile, 1};
   }
   if (batch != 1) return best;
   // Cutting K (the reference does it for its tall-skinny class only,
@@ -555,7 +558,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     case SBAMD_KERNEL_TINY: plan = {TILE_32, 1}; break;
     case SBAMD_KERNEL_NAIVE: plan = {TILE_NAIVE, 1}; break;
     case SBAMD_KERNEL_MEDIUM:  // parameter bit 0: the 192 x 192 tile
-      if (sizeof(T) == 4) plan = {(h->kernel_param & 1) ? TILE_192 : TILE_96, 1};
+      plan = {(h->kernel_param & 1) ? TILE_192 : TILE_96, 1};
       break;
     case SBAMD_KERNEL_SPLITK:
       if (pin_tile >= TILE_64 && pin_tile <= TILE_256) plan.tile = pin_tile;
@@ -580,13 +583,11 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     return launch_tile<T, 32, 32, Tiles<T>::TINY_BK, 1, 1, 4>(g, p.ta, p.tb, h->stream);
   }
   if (plan.tile == TILE_96 || plan.tile == TILE_192) {
-    if constexpr (sizeof(T) == 4) {
-      h->last_kernel = SBAMD_KERNEL_MEDIUM;
-      if (plan.tile == TILE_192) return launch_tile<T, 192, 192, 32, 2, 4, 2, MfmaF32Small>(g, p.ta, p.tb, h->stream);
-      return launch_tile<T, 96, 96, 32, 2, 2, 2, MfmaF32Small>(g, p.ta, p.tb, h->stream);
-    } else {
-      plan.tile = TILE_64;
-    }
+    using MS = typename Tiles<T>::MediumShape;
+    h->last_kernel = SBAMD_KERNEL_MEDIUM;
+    if (plan.tile == TILE_192)
+      return launch_tile<T, 192, 192, Tiles<T>::MEDIUM_BK, 2, 4, sizeof(T) == 4 ? 2 : 1, MS>(g, p.ta, p.tb, h->stream);
+    return launch_tile<T, 96, 96, Tiles<T>::MEDIUM_BK, 2, 2, 2, MS>(g, p.ta, p.tb, h->stream);
   }
 
   const int bk = plan.tile == TILE_256 ? Tiles<T>::HUGE_BK : plan.tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;

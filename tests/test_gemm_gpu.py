@@ -56,7 +56,7 @@ FAMILY_SHAPES = [(1, 1, 1), (7, 9, 5), (33, 65, 31), (64, 64, 64), (129, 127, 70
 def test_every_kernel_family(sb_handle, family, dtype):
     sb_handle.set_kernel(getattr(_lib, "KERNEL_" + family))
     try:
-        if family == "MEDIUM" and dtype == np.float32:  # its second tile (192 x 192): parameter bit 0
+        if family == "MEDIUM":  # its second tile (192 x 192): parameter bit 0
             sb_handle.set_kernel(_lib.KERNEL_MEDIUM, 1)
             for (m, n, k), ta, tb in itertools.product([(200, 260, 133), (385, 193, 70), (192, 384, 64)], "nt", "nt"):
                 verify_gemm(sb_handle, dtype, 3, 1, m, n, k, ta, tb, 1.5, 0.5, 2, 2, 2)
@@ -65,10 +65,7 @@ def test_every_kernel_family(sb_handle, family, dtype):
         for (m, n, k), ta, tb, (off, ldm) in itertools.product(FAMILY_SHAPES, "nt", "nt", [(0, 1), (3, 2)]):
             for alpha, beta in ((1.5, 0.5), (-2.0, 0.0)):
                 verify_gemm(sb_handle, dtype, off, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
-            if family == "MEDIUM" and dtype != np.float32:  # the 96 x 96 tile is a float tile: double chooses by itself
-                assert sb_handle.last_kernel() != _lib.KERNEL_MEDIUM
-            else:
-                assert sb_handle.last_kernel() == getattr(_lib, "KERNEL_" + family)
+            assert sb_handle.last_kernel() == getattr(_lib, "KERNEL_" + family)
     finally:
         sb_handle.set_kernel(_lib.KERNEL_AUTO)
 

@@ -132,6 +132,14 @@ int main(int argc, char** argv) {
     if (run<float, 192, 192, 32, 2, 4, 2, false, true, MfmaF32Small>("f32 192x192x32 NT (16x16x4, 8 waves of 96x48)", 3072, 20)) return 1;
     if (run<float, 192, 192, 32, 2, 4, 2, true, false, MfmaF32Small>("f32 192x192x32 TN (16x16x4, 8 waves of 96x48)", 3072, 20)) return 1;
     if (run<float, 192, 96, 32, 2, 2, 2, false, false, MfmaF32Small>("f32 192x96x32 NN (16x16x4, 4 waves of 96x48)", 3072, 20)) return 1;
+  } else if (mode == 'd') {  // the same tile edges for double (its instruction is 16x16x4 already)
+    for (int n : {1536, 3072}) {
+      const int reps = n == 3072 ? 10 : 50;
+      if (run<double, 64, 64, 16, 2, 2, 2, false, false>("f64 64x64x16 NN", n, reps)) return 1;
+      if (run<double, 128, 128, 16, 2, 2, 2, false, false>("f64 128x128x16 NN", n, reps)) return 1;
+      if (run<double, 96, 96, 16, 2, 2, 2, false, false>("f64 96x96x16 NN (4 waves of 48x48)", n, reps)) return 1;
+      if (run<double, 192, 192, 16, 2, 4, 1, false, false>("f64 192x192x16 NN (8 waves of 96x48)", n, reps)) return 1;
+    }
   } else if (mode == 'l') {
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 4096, 20)) return 1;
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 2048, 100)) return 1;
