@@ -10,7 +10,7 @@ for row in rows:
     dt, ta, tb, m, k, n, bs, kern, tile, depth, ms = row[:11]
     fused = int(row[11]) if len(row) > 11 else 0  # both K halves inside one workgroup
     by[(int(m), int(n), int(k))].append((float(ms), int(kern), int(tile), int(depth), fused))
-names = {0: "auto", 1: "large", 2: "small", 3: "splitk", 4: "naive", 5: "huge"}
+names = {0: "auto", 1: "large", 2: "small", 3: "splitk", 4: "naive", 5: "huge", 7: "tiny", 8: "stream", 9: "medium"}
 print("shape (m,n,k)          auto_us  best_us  best             auto/best")
 worst = []
 for key, c in by.items():
