@@ -106,6 +106,16 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
       cands.push_back({"naive  one element per lane", SBAMD_KERNEL_NAIVE, 0, true});
   }
 
+  // The first launches of a process run at a lower clock: spend a few milliseconds before timing anything, or the
+  // first candidate ("auto") reads up to 1.5x slow on microsecond-sized shapes.
+  {
+    check(sbamd_set_kernel(h, SBAMD_KERNEL_AUTO, 0), h, "set_kernel");
+    const double est_us = std::max(5.0, 2.0 * double(m) * double(n) * double(k) * double(bs) / 50e6);
+    const int warm = int(std::min(200.0, std::max(3.0, 3000.0 / est_us)));
+    for (int i = 0; i < warm; ++i)
+      check(gemm_call<T>(h, ta, tb, m, n, k, (const T*)a, lda, (const T*)b, ldb, (T*)c, ldc, bs, batch_type), h, "gemm");
+    check(sbamd_wait(h), h, "wait");
+  }
   std::vector<T> first, got(static_cast<size_t>(nc));
   std::vector<Outcome> outcomes;
   const double flops = 2.0 * double(m) * double(n) * double(k) * double(bs);
