@@ -28,11 +28,13 @@ with sb.SB_Handle(0) as h:
         beta = float(rng.choice([0.0, 1.0, 0.5]))
         ldm = int(rng.choice([1, 1, 2]))
         offset = int(rng.choice([0, 0, v, 7]))
-        mode = int(rng.integers(0, 6))
+        mode = int(rng.integers(0, 7))
         if mode == 0:
             h.set_kernel(_lib.KERNEL_SMALL)
         elif mode == 1:
             h.set_kernel(_lib.KERNEL_SPLITK, int(rng.choice([2, 3, 4, 5])) | (int(rng.integers(1, 4)) << 16) | (int(rng.integers(0, 2)) << 24))
+        elif mode == 6:
+            h.set_kernel(_lib.KERNEL_MEDIUM, int(rng.integers(0, 2)))
         else:
             h.set_kernel(_lib.KERNEL_AUTO)
         if mode == 5:
@@ -42,6 +44,17 @@ with sb.SB_Handle(0) as h:
             verify_gemm(h, dtype, offset, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
         if i % 25 == 0:
             print(f"case {i}: {np.dtype(dtype).name} {m}x{n}x{k} {ta}{tb} mode {mode} kernel {h.last_kernel()} cut {h.last_splitk()}", flush=True)
+    # mid-size products, where the planner's own choice is often the 96- or 192-row tile
+    h.set_kernel(_lib.KERNEL_AUTO)
+    for i in range(16):
+        dtype = np.float32 if rng.integers(0, 2) else np.float64
+        m, n = int(rng.integers(600, 1800)), int(rng.integers(600, 1800))
+        if rng.integers(0, 2):
+            m, n = (m + 95) // 96 * 96, (n + 95) // 96 * 96
+        k = int(rng.integers(40, 260))
+        ta, tb = str(rng.choice(["n", "t"])), str(rng.choice(["n", "t"]))
+        verify_gemm(h, dtype, 0, 1, m, n, k, ta, tb, 1.5, float(rng.choice([0.0, 0.5])), 1, 1, 1)
+        print(f"mid case {i}: {np.dtype(dtype).name} {m}x{n}x{k} {ta}{tb} kernel {h.last_kernel()} cut {h.last_splitk()}", flush=True)
     # long batches of single-tile items
     h.set_kernel(_lib.KERNEL_AUTO)
     for i in range(12):
