@@ -13,6 +13,7 @@
 // than split-K must agree bit for bit.
 #include <algorithm>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -105,16 +106,18 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     if (double(m) * double(n) * double(k) * double(bs) <= 8e9)  // the scalar kernel is for checking, keep it short
       cands.push_back({"naive  one element per lane", SBAMD_KERNEL_NAIVE, 0, true});
   }
+  if (std::getenv("SBAMD_TUNE_AUTO_TWICE")) cands.push_back({"auto (again, last)", SBAMD_KERNEL_AUTO, 0, false});
 
-  // The first launches of a process run at a lower clock: spend a few milliseconds before timing anything, or the
-  // first candidate ("auto") reads up to 1.5x slow on microsecond-sized shapes.
+  // The first launches of a process run at a lower clock, and the ramp takes tens of milliseconds: keep the device
+  // busy for that long before timing anything, or the first candidate ("auto") reads 1.2x to 1.5x slow.
   {
     check(sbamd_set_kernel(h, SBAMD_KERNEL_AUTO, 0), h, "set_kernel");
-    const double est_us = std::max(5.0, 2.0 * double(m) * double(n) * double(k) * double(bs) / 50e6);
-    const int warm = int(std::min(200.0, std::max(3.0, 3000.0 / est_us)));
-    for (int i = 0; i < warm; ++i)
-      check(gemm_call<T>(h, ta, tb, m, n, k, (const T*)a, lda, (const T*)b, ldb, (T*)c, ldc, bs, batch_type), h, "gemm");
-    check(sbamd_wait(h), h, "wait");
+    const auto t0 = std::chrono::steady_clock::now();
+    do {
+      for (int i = 0; i < 4; ++i)
+        check(gemm_call<T>(h, ta, tb, m, n, k, (const T*)a, lda, (const T*)b, ldb, (T*)c, ldc, bs, batch_type), h, "gemm");
+      check(sbamd_wait(h), h, "wait");
+    } while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(80));
   }
   std::vector<T> first, got(static_cast<size_t>(nc));
   std::vector<Outcome> outcomes;
@@ -142,6 +145,16 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
       if (o.cand.exact) {
         if (first.empty()) first = got;
         else o.same_bits = std::memcmp(first.data(), got.data(), got.size() * sizeof(T)) == 0;
+      }
+      // The clock the chip holds depends on what it ran in the last milliseconds (a candidate timed right after a
+      // run of short, light launches read up to 9 % faster than the same kernel timed after a heavy one): give
+      // every candidate 15 ms of its own launches before its timed loop.
+      {
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+          for (int i = 0; i < 4; ++i) check(call(), h, "gemm");
+          check(sbamd_wait(h), h, "wait");
+        } while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(15));
       }
       sbamd_event_t e0 = nullptr, e1 = nullptr;
       check(sbamd_event_record(h, &e0), h, "event");

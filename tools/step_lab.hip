@@ -140,6 +140,15 @@ int main(int argc, char** argv) {
       if (run<double, 96, 96, 16, 2, 2, 2, false, false>("f64 96x96x16 NN (4 waves of 48x48)", n, reps)) return 1;
       if (run<double, 192, 192, 16, 2, 4, 1, false, false>("f64 192x192x16 NN (8 waves of 96x48)", n, reps)) return 1;
     }
+  } else if (mode == 'v') {  // deeper K steps on the 64 x 64 tile at 1024^3 (one tile per compute unit): the step of 128 reads
+    // 22.3 us against 24.2 here, on the null stream; through the library's stream and entry point it read 24.3 against
+    // 23.5 for the planner's choice (two K halves per workgroup), and slower still for A read along K -- not taken
+    if (run<float, 64, 64, 32, 2, 2, 2, false, false>("f32 64x64x32 NN", 1024, 200)) return 1;
+    if (run<float, 64, 64, 64, 2, 2, 2, false, false>("f32 64x64x64 NN", 1024, 200)) return 1;
+    if (run<float, 64, 64, 128, 2, 2, 1, false, false>("f32 64x64x128 NN", 1024, 200)) return 1;
+    if (run<float, 64, 64, 128, 2, 2, 1, false, false, MfmaF32Small>("f32 64x64x128 NN (16x16x4)", 1024, 200)) return 1;
+    if (run<float, 64, 64, 128, 2, 2, 1, false, true>("f32 64x64x128 NT", 1024, 200)) return 1;
+    if (run<float, 64, 64, 128, 2, 2, 1, true, false>("f32 64x64x128 TN", 1024, 200)) return 1;
   } else if (mode == 'l') {
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 4096, 20)) return 1;
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 2048, 100)) return 1;
