@@ -84,7 +84,7 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     cands.push_back({sizeof(T) == 4 ? "large  128x128 tile, 8 waves" : "large  128x128 tile, 4 waves", SBAMD_KERNEL_LARGE, 0, true});
     cands.push_back({"small   64x64  tile, 4 waves", SBAMD_KERNEL_SMALL, 0, true});
     cands.push_back({"small   64x64  tile, register-staged only", SBAMD_KERNEL_SMALL, 1, true});
-    if (m <= 64 && n <= 64) cands.push_back({"tiny    32x32  tile, 1 wave", SBAMD_KERNEL_TINY, 0, true});
+    if (m * n * bs <= 1024 * 1024) cands.push_back({"tiny    32x32  tile, 1 wave", SBAMD_KERNEL_TINY, 0, true});
     if (bs == 1) {
       static const char* tile_names[] = {"", "64x64", "128x128", sizeof(T) == 4 ? "256x256" : "256x128"};
       for (int tile = 1; tile <= 3; ++tile)

@@ -316,30 +316,39 @@ struct CostOverheads {
 };
 template <>
 struct CostModel<float> {
-  // fitted to the sweep taken after the 64 x 64 K loop got its fragments two groups ahead and its operand
-  // traffic spread over the step (one workgroup per compute unit: 0.0237 -> 0.0181 us per unit of K)
-  static constexpr double small_k[4] = {0.0181, 0.0372, 0.0555, 0.0726};
-  static constexpr double large_k[2] = {0.0700, 0.1223};  // one per unit: 0.0695-0.0754 measured with every unit busy (the fit, pulled down by launches that leave units idle, said 0.0617)
-  static constexpr double huge_k[1] = {0.2416};  // 256 x 256 tile
-  // 96 x 96 tile on the 16x16x4 instruction, one / two workgroups per unit (1536^3, 256 tiles: 64.5 us; 3072^3,
-  // 1024 tiles: 454 us; tools/step_lab.hip m)
-  static constexpr double medium_k[2] = {0.0394, 0.0732};
+  // Fitted to a sweep in which every candidate was timed after 15 ms of its own launches (timed cold, right after
+  // whatever ran before, candidates read up to 9 % apart from themselves and the fit carried that noise:
+  // small_k {0.0181, 0.0372, 0.0555, 0.0726}, large_k {0.0700, 0.1223}, huge_k 0.2416 before).  The fit said
+  // small_k {0.0175, 0.0338, 0.0506, 0.0657}, large_k {0.0605, 0.1155}, huge_k 0.2395; entries it gets mostly
+  // from short K slabs are set from long single launches instead: 64 x 64 alone on a unit 0.0181 (1024^3) and
+  // 0.0179 (1024 x 1024 x 16384), with company 0.0364 (1024 x 2048 x 4096); 128 x 128 0.0621 (2048 x 2048 x 1024)
+  // and, two per unit, 0.1166 over 8192^3's eight rounds (0.1233 over 4096^3's two, which start and end together);
+  // 256 x 256 0.2286 at 8192^3 and 0.2339 at 4096^3 -- it has to stay ahead of 128 x 128 on both, as measured.
+  static constexpr double small_k[4] = {0.0180, 0.0355, 0.0530, 0.0690};
+  static constexpr double large_k[2] = {0.0620, 0.1165};
+  static constexpr double huge_k[1] = {0.2300};  // 256 x 256 tile
+  // 96 x 96 tile on the 16x16x4 instruction, one / two workgroups per unit (medians over the sweep's shapes with
+  // at least 200 such tiles; 1536^3, 256 tiles: 64.5 us; 3072^3, 1024 tiles: 454 us)
+  static constexpr double medium_k[2] = {0.0400, 0.0748};
   // 192 x 192 tile on the same instruction, eight wavefronts of 96 x 48, one workgroup per unit (3072^3, 256 tiles: 415 us)
-  static constexpr double wide_k[1] = {0.1340};
+  static constexpr double wide_k[1] = {0.1350};
   // two K halves in one workgroup, relative to two resident workgroups of the tile {64x64, 128x128}
   // (medians over the sweep's shapes that leave at least half of a unit's workgroup slots empty)
-  static constexpr double halves_factor[2] = {0.903, 0.986};
-  static constexpr CostOverheads over = {4.21, 7.29, 5.32e6, 0.0467};
+  static constexpr double halves_factor[2] = {1.020, 1.046};
+  static constexpr CostOverheads over = {3.66, 6.98, 5.87e6, 0.0498};
 };
 template <>
 struct CostModel<double> {
-  // refitted after the 64 x 64 kernel lost its accumulator copies (one workgroup per unit: 0.0460 -> 0.0380 us)
+  // refitted after the 64 x 64 kernel lost its accumulator copies (one workgroup per unit: 0.0460 -> 0.0380 us).
+  // A refit to the sweep with every candidate timed after 15 ms of its own launches (small_k {0.0366, 0.0724,
+  // 0.0915, 0.1205}, large_k {0.1193, 0.2317}, halves {0.872, 0.997}) chose worse on that same sweep (auto / best
+  // 90th percentile 1.10 against 1.07 with these), for the reason given at float's constants; these stay.
   static constexpr double small_k[4] = {0.0380, 0.0785, 0.1027, 0.1300};
   static constexpr double large_k[2] = {0.1205, 0.2393};
   static constexpr double huge_k[1] = {0.2346};
   // 96 x 96 (1536^3: 112 us against 149 on 64 x 64; 3072^3: 822 us) and 192 x 192 (3072^3: 805 us), tools/step_lab.hip d
-  static constexpr double medium_k[2] = {0.0697, 0.1330};
-  static constexpr double wide_k[1] = {0.2604};
+  static constexpr double medium_k[2] = {0.0705, 0.1380};
+  static constexpr double wide_k[1] = {0.2640};
   static constexpr double halves_factor[2] = {0.807, 0.967};
   static constexpr CostOverheads over = {5.12, 7.20, 5.83e6, 0.0397};
 };
@@ -406,6 +415,11 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
   if (batch > 1 && m <= 32 && n <= 32) return {TILE_32, 1};
   // Short K (the batched 64x64x64 class) has a kernel of its own on the small tile.
   if (k <= Tiles<T>::ONESHOT_BK && m <= 64 && n <= 64) return {TILE_64, 1};
+  // One short product with at most one 64 x 64 tile per unit: the one-wave 32 x 32 tile spreads it over four times
+  // as many wavefront slots (512 x 512 x 16: 4.2 -> 3.1 us; 256 x 256 x 49: 5.5 -> 4.3; 2048 x 512 x 49: 5.9 -> 5.0;
+  // fp64 100 x 700 x 30: 6.7 -> 4.6).
+  if (batch == 1 && k <= 64 && ceil_div(m, 64) * ceil_div(n, 64) <= cus && ceil_div(m, 32) * ceil_div(n, 32) >= 4)
+    return {TILE_32, 1};
   Plan best = {TILE_64, 1};
   double best_us = 1e300;
   for (int tile = TILE_64; tile <= TILE_256; ++tile) {
@@ -414,9 +428,9 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
   }
   // The 96 x 96 and 192 x 192 tiles: where the other tile counts quantise badly over the units (fp32 1536^3: 576
   // tiles of 64 x 64 are three on the busiest unit, 256 tiles of 96 x 96 one each: 84 -> 65 us; 3072^3: 256 tiles
-  // of 192 x 192, 489 -> 415 us).  Their constants come from two shapes each, so they have to win by 6 %.
+  // of 192 x 192, 489 -> 415 us).  Their constants come from fewer shapes than the others', so they have to win by 3 %.
   for (int tile : {TILE_96, TILE_192}) {
-    const double us = 1.06 * estimate_us<T>(tile, 1, m, n, k, batch, cus);
+    const double us = 1.03 * estimate_us<T>(tile, 1, m, n, k, batch, cus);
     if (us < best_us) best_us = us, best = {tile, 1};
   }
   if (batch != 1) return best;

@@ -140,9 +140,10 @@ int main(int argc, char** argv) {
       if (run<double, 96, 96, 16, 2, 2, 2, false, false>("f64 96x96x16 NN (4 waves of 48x48)", n, reps)) return 1;
       if (run<double, 192, 192, 16, 2, 4, 1, false, false>("f64 192x192x16 NN (8 waves of 96x48)", n, reps)) return 1;
     }
-  } else if (mode == 'v') {  // deeper K steps on the 64 x 64 tile at 1024^3 (one tile per compute unit): the step of 128 reads
-    // 22.3 us against 24.2 here, on the null stream; through the library's stream and entry point it read 24.3 against
-    // 23.5 for the planner's choice (two K halves per workgroup), and slower still for A read along K -- not taken
+  } else if (mode == 'v') {  // deeper K steps on the 64 x 64 tile at 1024^3 (one tile per compute unit).  Read with care: run
+    // back to back here the step of 128 read 22.3 us against 24.2, but behind the library's entry point, each form
+    // timed after 15 ms of its own launches (benchmark/tune_gemm), every form of the 64 x 64 tile reads 22.1-22.3 us
+    // at 1024^3, and the step of 128 is 6 % slower at 1000^3 and 4 % at 4096 x 512 x 4096 -- not taken
     if (run<float, 64, 64, 32, 2, 2, 2, false, false>("f32 64x64x32 NN", 1024, 200)) return 1;
     if (run<float, 64, 64, 64, 2, 2, 2, false, false>("f32 64x64x64 NN", 1024, 200)) return 1;
     if (run<float, 64, 64, 128, 2, 2, 1, false, false>("f32 64x64x128 NN", 1024, 200)) return 1;
