@@ -10,7 +10,9 @@
 // pinned through sbamd_set_kernel, plus what the dispatcher picks by itself
 // ("auto"), so a shape where "auto" is not last in the list is a dispatch-table bug.
 // Every candidate's result is compared with the first candidate's: families other
-// than split-K must agree bit for bit.
+// than split-K must agree bit for bit.  Each candidate is timed after 15 ms of its own launches (the clock the chip
+// holds depends on what ran just before); with SBAMD_TUNE_AUTO_TWICE set in the environment "auto" is timed a
+// second time as the last candidate, as a check on that.
 #include <algorithm>
 #include <cstdint>
 #include <chrono>

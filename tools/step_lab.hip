@@ -150,6 +150,14 @@ int main(int argc, char** argv) {
     if (run<float, 64, 64, 128, 2, 2, 1, false, false, MfmaF32Small>("f32 64x64x128 NN (16x16x4)", 1024, 200)) return 1;
     if (run<float, 64, 64, 128, 2, 2, 1, false, true>("f32 64x64x128 NT", 1024, 200)) return 1;
     if (run<float, 64, 64, 128, 2, 2, 1, true, false>("f32 64x64x128 TN", 1024, 200)) return 1;
+  } else if (mode == 'w') {  // 64 x 64 tile on eight wavefronts of the 16x16x4 instruction (two per SIMD, no K cut), one tile per unit:
+    // 1024^3 22.7 us (16 x 32 wave tiles, K step 64) to 24.9 us against 22.0-22.1 for the four wavefronts of 32 x 32 -- not taken
+    if (run<float, 64, 64, 64, 2, 2, 2, false, false>("f32 64x64x64 NN (4 waves of 32x32, 32x32x2)", 1024, 400)) return 1;
+    if (run<float, 64, 64, 32, 4, 2, 2, false, false, MfmaF32Small>("f32 64x64x32 NN (8 waves of 16x32, 16x16x4)", 1024, 400)) return 1;
+    if (run<float, 64, 64, 32, 2, 4, 2, false, false, MfmaF32Small>("f32 64x64x32 NN (8 waves of 32x16, 16x16x4)", 1024, 400)) return 1;
+    if (run<float, 64, 64, 64, 4, 2, 2, false, false, MfmaF32Small>("f32 64x64x64 NN (8 waves of 16x32, 16x16x4)", 1024, 400)) return 1;
+    if (run<float, 64, 64, 64, 2, 4, 2, false, false, MfmaF32Small>("f32 64x64x64 NN (8 waves of 32x16, 16x16x4)", 1024, 400)) return 1;
+    if (run<float, 64, 64, 64, 2, 2, 2, false, false>("f32 64x64x64 NN (4 waves of 32x32, 32x32x2) again", 1024, 400)) return 1;
   } else if (mode == 'l') {
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 4096, 20)) return 1;
     if (run<float, 128, 128, 32, 4, 2, 2, false, false>("f32 128x128x32 NN (8 waves of 32x64)", 2048, 100)) return 1;
