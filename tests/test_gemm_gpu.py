@@ -224,3 +224,20 @@ def test_short_k_products_walk_their_tiles(sb_handle, dtype):
     for args in ((0, 1, m - 4, n, 64), (0, 1, m, n, 96), (1, 1, m, n, 64), (0, 1, 1024, 1024, 64)):
         verify_gemm(sb_handle, dtype, *args, "n", "n", 1.0, 0.5, 1, 1, 1)
         assert sb_handle.last_kernel() != _lib.KERNEL_STREAM
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_short_products_with_few_tiles_take_the_one_wave_tile(sb_handle, dtype):
+    # One product with K <= 64 and at most one 64 x 64 tile per compute unit runs on the one-wave 32 x 32 tile
+    # (four times as many workgroups over the chip).  Same chain per element: whole buffers equal the oracle bit
+    # for bit, for every transpose, ragged edges and multiplied leading dimensions included.
+    sb_handle.set_kernel(_lib.KERNEL_AUTO)
+    for (m, n, k) in ((512, 512, 16), (100, 700, 30), (2048, 512, 49), (256, 250, 64), (33, 65, 7)):
+        for ta, tb in itertools.product("nt", "nt"):
+            verify_gemm(sb_handle, dtype, 0, 1, m, n, k, ta, tb, 1.5, 0.5, 1, 2, 1)
+            assert sb_handle.last_kernel() == _lib.KERNEL_TINY
+            assert sb_handle.last_splitk()[0] == 1
+    # a single tile, a longer K or a batch keep their own families
+    for args in ((1, 60, 60, 40), (1, 512, 512, 96), (3, 200, 200, 32)):
+        verify_gemm(sb_handle, dtype, 0, *args, "n", "t", 1.0, 0.0, 1, 1, 1)
+        assert sb_handle.last_kernel() != _lib.KERNEL_TINY
