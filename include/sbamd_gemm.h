@@ -52,7 +52,7 @@ enum {
   SBAMD_TRSM_INVALID_UPLO = 15,  /* "invalid Triangle argument"    trsm_interface.hpp:126 */
   SBAMD_TRSM_INVALID_TRANS = 16, /* "invalid Transpose argument"   trsm_interface.hpp:128 */
   SBAMD_TRSM_INVALID_DIAG = 17,  /* "invalid Diagonal argument"    trsm_interface.hpp:130 */
-  SBAMD_SCRATCH_TOO_SMALL = 18   /* sbamd_sgemm_noalloc only: the call's split-K cube exceeds the fixed array */
+  SBAMD_SCRATCH_TOO_SMALL = 18   /* sbamd_sgemm_noalloc only: a pinned split-K cut whose cube exceeds the fixed array */
 };
 
 /* Batch layouts: include/operations/blas3_trees.h:59 (gemm_batch_type_t). */
@@ -209,13 +209,18 @@ int sbamd_bsgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t 
 
 /* sbamd_sgemm for callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
- * no counterpart in the reference.  Same arguments, same kernels, same result
- * bit for bit as sbamd_sgemm; the only difference is where a split-K call keeps
- * its partial products: in a fixed array of SBAMD_NOALLOC_SCRATCH_BYTES that
- * every GPU the library runs on holds until the process ends, instead of the
- * handle's on-demand buffer.  The call makes no hipMalloc / hipFree.  A call
- * whose cube (m * n * depth floats; sbamd_last_splitk reports depth) does not
- * fit returns SBAMD_SCRATCH_TOO_SMALL and launches nothing.  All handles on one
+ * no counterpart in the reference.  Same arguments and same kernels as
+ * sbamd_sgemm; the only difference is where a split-K call keeps its partial
+ * products: in a fixed array of SBAMD_NOALLOC_SCRATCH_BYTES that every GPU the
+ * library runs on holds until the process ends, instead of the handle's
+ * on-demand buffer.  The call makes no hipMalloc / hipFree and does not use or
+ * touch the handle's own buffers.  The planner only considers K cuts whose cube
+ * (m * n * depth floats) fits the array, so a shape whose preferred cut would
+ * not fit runs with the best cut that does, or as a single launch; the result
+ * equals sbamd_sgemm's bit for bit whenever both cut K the same way
+ * (sbamd_last_splitk reports the cut of either).  Only a cut pinned with
+ * sbamd_set_kernel(SBAMD_KERNEL_SPLITK, depth) that does not fit is refused:
+ * SBAMD_SCRATCH_TOO_SMALL, nothing launched, C untouched.  All handles on one
  * GPU share that GPU's array: calls through this entry point that overlap in
  * time on one GPU (different streams or host threads) race on it; calls on one
  * stream are ordered and safe.  Nothing in the array has to start at zero (every

@@ -53,6 +53,13 @@ def load():
                                       C.c_double, vp, i64, vp, vp, i64]
     lib.oracle_compare_f64.restype = i64
     lib.oracle_compare_f64.argtypes = [vp, vp, i64, C.c_double, C.c_double]
+    lib.oracle_gemm_half_chain.restype = C.c_int
+    lib.oracle_gemm_half_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, i64, C.c_uint16, vp, i64, vp,
+                                           i64, C.c_uint16, vp, i64]
+    lib.oracle_half_from_double.restype = None
+    lib.oracle_half_from_double.argtypes = [vp, vp, i64]
+    lib.oracle_half_to_double.restype = None
+    lib.oracle_half_to_double.argtypes = [vp, vp, i64]
     lib.oracle_default_strides.restype = None
     lib.oracle_default_strides.argtypes = [C.c_char, C.c_char, i64, i64, i64, i64, i64, i64,
                                            C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
@@ -108,6 +115,35 @@ def default_strides(transa, transb, m, n, k, lda, ldb, ldc):
     load().oracle_default_strides(_ch(transa), _ch(transb), m, n, k, lda, ldb, ldc, C.byref(sa),
                                   C.byref(sb), C.byref(sc))
     return sa.value, sb.value, sc.value
+
+
+def half_from_double(x):
+    """The oracle's own round-to-nearest-even double -> binary16 conversion (bit patterns)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(x.shape, dtype=np.uint16)
+    load().oracle_half_from_double(x.ctypes.data, out.ctypes.data, x.size)
+    return out
+
+
+def half_to_double(bits):
+    bits = np.ascontiguousarray(bits, dtype=np.uint16)
+    out = np.empty(bits.shape, dtype=np.float64)
+    load().oracle_half_to_double(bits.ctypes.data, out.ctypes.data, bits.size)
+    return out
+
+
+def gemm_half_chain(transa, transb, m, n, k, alpha, a_bits, lda, b_bits, ldb, beta, c_bits, ldc, form=FORM_LOCAL,
+                    fused=True, a_off=0, b_off=0, c_off=0):
+    """One half -> half GEMM in the reference's own arithmetic for that pair: accumulator, alpha, beta and every
+    operation in binary16 (src/operations/blas3/gemm_common.hpp:45-51).  Arrays are uint16 bit patterns; c_bits is
+    updated in place.  form: FORM_LOCAL (the tiled kernels, the default) or FORM_REF (the naive kernel)."""
+    for x in (a_bits, b_bits, c_bits):
+        assert x.dtype == np.uint16 and x.flags["C_CONTIGUOUS"]
+    al = int(np.float16(alpha).view(np.uint16))
+    be = int(np.float16(beta).view(np.uint16))
+    return load().oracle_gemm_half_chain(int(form), int(bool(fused)), int(transa.lower() != "n"),
+                                         int(transb.lower() != "n"), m, n, k, al, a_bits.ctypes.data + 2 * a_off, lda,
+                                         b_bits.ctypes.data + 2 * b_off, ldb, be, c_bits.ctypes.data + 2 * c_off, ldc)
 
 
 def gemm_truth(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):

@@ -565,3 +565,88 @@ int64_t oracle_compare_f64(const double* vec, const double* ref, int64_t count, 
   }
   return -1;
 }
+
+/* ---------------------------------------------------------------- half -> half
+ * The reference's arithmetic for the half -> half pair.  With Tin == Tout its mul_add is
+ * sycl::mad(half, half, half) (src/operations/blas3/gemm_common.hpp:45-51): the accumulator
+ * lives in binary16 and every k step rounds to binary16 -- unlike the half -> float pair,
+ * which widens both operands first (:53-59).  alpha, beta and every epilogue operation are
+ * binary16 too (src/interface/blas3/gemm.cpp.in:33-39).
+ *
+ * binary16 values are carried as bit patterns and the arithmetic runs in double: a product of
+ * two binary16 values has 22 significant bits (exact in double), and the sum of that product
+ * and a binary16 accumulator is rounded to 53 bits before it is rounded to 11 -- which cannot
+ * change the result: the first rounding only happens when the two terms are more than 2^30
+ * apart, and then the 53-bit value is never a binary16 tie that the exact sum is not.  So
+ * fused(a, b, c) below is the correctly rounded binary16 fma.  sycl::mad leaves it to the
+ * device whether the product is rounded on its own; `fused` == 0 restates that unfused variant. */
+static double half_bits_to_double(uint16_t h) {
+  const int sign = h >> 15, e = (h >> 10) & 31, man = h & 1023;
+  double v;
+  if (e == 31) v = man ? NAN : INFINITY;
+  else if (e == 0) v = ldexp((double)man, -24);
+  else v = ldexp((double)(man | 1024), e - 25);
+  return sign ? -v : v;
+}
+
+/* round-to-nearest-even double -> binary16 (overflow to infinity, gradual underflow) */
+static uint16_t double_to_half_bits(double d) {
+  uint64_t u;
+  memcpy(&u, &d, sizeof u);
+  const uint16_t sign = (uint16_t)((u >> 48) & 0x8000u);
+  const int e = (int)((u >> 52) & 0x7ff);
+  uint64_t man = u & 0xfffffffffffffULL;
+  if (e == 0x7ff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0u));
+  if (e == 0) return sign; /* zero or a double subnormal: far below half the smallest binary16 */
+  const int he = e - 1023 + 15;
+  if (he >= 31) return (uint16_t)(sign | 0x7c00u);
+  man |= (uint64_t)1 << 52;
+  int shift = 42; /* 53-bit significand -> 11 bits */
+  if (he <= 0) shift += 1 - he;
+  if (shift > 63) return sign;
+  uint64_t q = man >> shift;
+  const uint64_t rem = man & (((uint64_t)1 << shift) - 1), tie = (uint64_t)1 << (shift - 1);
+  if (rem > tie || (rem == tie && (q & 1))) ++q;
+  /* normal: q in [1024, 2048]; q - 1024 added to the exponent field carries by itself */
+  const uint32_t out = he <= 0 ? (uint32_t)q : ((uint32_t)he << 10) + (uint32_t)(q - 1024);
+  return (uint16_t)(sign | (out >= 0x7c00u ? 0x7c00u : out));
+}
+
+static double rh(double x) { return half_bits_to_double(double_to_half_bits(x)); }
+
+void oracle_half_from_double(const double* in, uint16_t* out, int64_t count) {
+  for (int64_t i = 0; i < count; ++i) out[i] = double_to_half_bits(in[i]);
+}
+void oracle_half_to_double(const uint16_t* in, double* out, int64_t count) {
+  for (int64_t i = 0; i < count; ++i) out[i] = half_bits_to_double(in[i]);
+}
+
+/* One half -> half GEMM with every operation rounded to binary16 (bit patterns in and out).
+ * form: ORC_FORM_REF   alpha*acc + beta*C, chain from zero (gemm_ref.hpp:234-251), or
+ *       ORC_FORM_LOCAL alpha*acc with the chain started at (beta/alpha)*C, the tiled kernels'
+ *                      form (gemm_local.hpp:182, :375-409, :557-581) -- the one the reference's
+ *                      AMD and DEFAULT back ends run for half (backend/default.hpp:150-199). */
+int oracle_gemm_half_chain(int form, int fused, int ta, int tb, int64_t m, int64_t n, int64_t k,
+                           uint16_t alpha_h, const uint16_t* a, int64_t lda, const uint16_t* b,
+                           int64_t ldb, uint16_t beta_h, uint16_t* c, int64_t ldc) {
+  if (form != ORC_FORM_REF && form != ORC_FORM_LOCAL) return ORC_INVALID_VALUE;
+  const double alpha = half_bits_to_double(alpha_h), beta = half_bits_to_double(beta_h);
+  const int beta_zero = (beta == 0.0);
+  const double ratio = rh(beta / alpha);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < m; ++i) {
+      uint16_t* cp = c + i + j * ldc;
+      double acc = 0.0;
+      if (form == ORC_FORM_LOCAL && !beta_zero) acc = rh(ratio * half_bits_to_double(*cp));
+      for (int64_t l = 0; l < k; ++l) {
+        const double av = half_bits_to_double(ta ? a[l + i * lda] : a[i + l * lda]);
+        const double bv = half_bits_to_double(tb ? b[j + l * ldb] : b[l + j * ldb]);
+        acc = fused ? rh(av * bv + acc) : rh(rh(av * bv) + acc);
+      }
+      double out = rh(alpha * acc);
+      if (form == ORC_FORM_REF && !beta_zero) out = rh(out + rh(beta * half_bits_to_double(*cp)));
+      *cp = double_to_half_bits(out);
+    }
+  return ORC_OK;
+}

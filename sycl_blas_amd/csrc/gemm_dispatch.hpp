@@ -406,7 +406,7 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
 }
 
 template <typename T>
-inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
+inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, double cube_limit = double(1u << 30)) {
   // Batches of tiny matrices (the shapes the reference's interleaved layout exists
   // for): a 64x64 tile would be mostly padding.  Up to 16x16 one lane per C element
   // wins (4^3 x 65536: 5.6 us against 244; 16^3 x 8192: 14 against 36), up to 32x32 a
@@ -444,7 +444,7 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus) {
   for (int tile = TILE_64; tile <= TILE_256; ++tile)
     for (int depth : depths) {
       if (k / depth < 64) break;                                                   // slabs of at least 64
-      if (double(m) * double(n) * depth * sizeof(T) > double(1u << 30)) break;     // cube of at most 1 GiB
+      if (double(m) * double(n) * depth * sizeof(T) > cube_limit) break;           // cube of at most 1 GiB (or what the caller provides)
       const double us = estimate_us<T>(tile, depth, m, n, k, 1, cus);
       if (us < split_us) split_us = us, split = {tile, depth};
     }
@@ -560,7 +560,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     return launch_stream<T, Tiles<T>::ONESHOT_BK, Tiles<T>::STREAM_OCC>(g, p.ta, p.tb, cus, h->stream);
   }
 
-  Plan plan = plan_gemm<T>(p.m, p.n, p.k, p.batch, cus);
+  Plan plan = p.cube ? plan_gemm<T>(p.m, p.n, p.k, p.batch, cus, double(p.cube_bytes)) : plan_gemm<T>(p.m, p.n, p.k, p.batch, cus);
   // A pinned family overrides the planner (testing / tuning hook).
   const int pin_depth = h->kernel_param & 0xffff, pin_tile = (h->kernel_param >> 16) & 0xff;
   const bool pin_fused = (h->kernel_param >> 24) & 1;
@@ -625,10 +625,16 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   }
   if (depth > 1) {
     const int64_t slice = p.m * p.n;
-    hipError_t e = ensure_scratch(h, size_t(slice) * depth * sizeof(T));
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    T* cube = static_cast<T*>(p.cube);
+    if (cube) {
+      if (size_t(slice) * depth * sizeof(T) > p.cube_bytes) return hipErrorOutOfMemory;  // only a pinned cut gets here
+    } else {
+      if ((e = ensure_scratch(h, size_t(slice) * depth * sizeof(T))) != hipSuccess) return e;
+      cube = static_cast<T*>(h->scratch);
+    }
     GemmArgs<T> gp = g;
-    gp.c = static_cast<T*>(h->scratch);
+    gp.c = cube;
     gp.ldc = p.m;
     gp.split_k = int32_t(depth);
     gp.k_chunk = k_chunk;
@@ -646,7 +652,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     if (e != hipSuccess) return e;
     const int64_t grid = ceil_div(slice, 256);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)grid), dim3(256), 0, h->stream,
-                       static_cast<const T*>(h->scratch), slice, int(depth), p.c, p.m, p.n, p.ldc, p.beta,
+                       static_cast<const T*>(cube), slice, int(depth), p.c, p.m, p.n, p.ldc, p.beta,
                        g.beta_zero);
     h->last_kernel = SBAMD_KERNEL_SPLITK;
     h->last_depth = depth;

@@ -41,14 +41,12 @@ static void release_retired(Handle* h, bool all) {
 // High-water-mark arena: a request that fits is served from what is there; a
 // bigger one gets a new allocation at once, and the old buffer -- which work
 // already queued on the stream may still read -- is parked with an event and
-// freed later.  The stream is never waited for here.
+// freed later, once that event has completed.  The handle's stream is not waited
+// for here (hipMalloc, and the hipFree of a parked buffer whose event has already
+// completed, are the only runtime calls that may block).
 static hipError_t grow(Handle* h, void** buf, size_t* have, size_t bytes) {
   std::lock_guard<std::mutex> lock(h->mu);
   if (bytes <= *have) return hipSuccess;
-  if (h->no_alloc) {
-    h->scratch_refused = true;
-    return hipErrorOutOfMemory;
-  }
   release_retired(h, false);
   const size_t rounded = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
   void* fresh = nullptr;
@@ -167,13 +165,15 @@ template <typename P>
 int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t n, int64_t k,
                  typename P::scal_t alpha, const typename P::in_t* a, int64_t lda, int64_t stride_a,
                  const typename P::in_t* b, int64_t ldb, int64_t stride_b, typename P::scal_t beta,
-                 typename P::out_t* c, int64_t ldc, int64_t stride_c, int64_t batch, int batch_type) {
+                 typename P::out_t* c, int64_t ldc, int64_t stride_c, int64_t batch, int batch_type,
+                 void* fixed_cube = nullptr, size_t fixed_cube_bytes = 0) {
   using TIn = typename P::in_t;
   using TOut = typename P::out_t;
   using TScal = typename P::scal_t;
   if (!hh) return SBAMD_INVALID_HANDLE;
   Handle* h = &hh->impl;
   if (m < 0 || n < 0 || k < 0 || batch < 0 || lda < 0 || ldb < 0 || ldc < 0) return SBAMD_INVALID_VALUE;
+  if (batch > 0x7fffffffLL) return SBAMD_INVALID_VALUE;  // the kernels carry the batch count in 32 bits
   if (batch_type != SBAMD_BATCH_STRIDED && batch_type != SBAMD_BATCH_INTERLEAVED) return SBAMD_INVALID_VALUE;
   DeviceGuard guard(h->device);
   if (!guard.ok) return SBAMD_HIP_ERROR;
@@ -247,10 +247,12 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   p.beta_zero = (beta == TScal(0));  // gemm_interface.hpp:92 (isZero)
   // One item has the same addresses in both layouts, so it takes the strided kernels.
   p.interleaved = batch_type == SBAMD_BATCH_INTERLEAVED && batch > 1;
+  p.cube = fixed_cube;
+  p.cube_bytes = fixed_cube_bytes;
   hipError_t e = P::run(h, p, alpha, beta);
   if (e == hipErrorNotSupported) return SBAMD_NOT_SUPPORTED;
-  if (h->no_alloc && h->scratch_refused) {
-    h->last_error = "the call needs more scratch than the fixed array of the no-allocation entry point holds";
+  if (fixed_cube && e == hipErrorOutOfMemory) {
+    h->last_error = "the pinned K cut needs more scratch than the fixed array of the no-allocation entry point holds";
     return SBAMD_SCRATCH_TOO_SMALL;
   }
   return e == hipSuccess ? SBAMD_OK : fail_hip(h, e, "gemm launch");
@@ -355,10 +357,12 @@ int sbamd_destroy(sbamd_handle_t h) {
 int sbamd_wait(sbamd_handle_t h) {
   if (!h) return SBAMD_INVALID_HANDLE;
   hipError_t e = hipStreamSynchronize(h->impl.stream);
-  if (e == hipSuccess && !h->impl.retired.empty()) {
-    DeviceGuard guard(h->impl.device);
+  if (e == hipSuccess) {
     std::lock_guard<std::mutex> lock(h->impl.mu);
-    release_retired(&h->impl, true);
+    if (!h->impl.retired.empty()) {
+      DeviceGuard guard(h->impl.device);
+      release_retired(&h->impl, true);
+    }
   }
   return e == hipSuccess ? SBAMD_OK : fail_hip(&h->impl, e, "stream synchronize");
 }
@@ -524,20 +528,10 @@ int sbamd_sgemm_noalloc(sbamd_handle_t h, char transa, char transb, int64_t m, i
   if (!h) return SBAMD_INVALID_HANDLE;
   Handle* hp = &h->impl;
   if (!hp->fixed_scratch) return SBAMD_HIP_ERROR;
-  // For the length of this call the cube is the device's fixed array and the
-  // arena refuses to grow; the handle's own buffers are put back afterwards.
-  void* const saved = hp->scratch;
-  const size_t saved_bytes = hp->scratch_bytes;
-  hp->scratch = hp->fixed_scratch;
-  hp->scratch_bytes = SBAMD_NOALLOC_SCRATCH_BYTES;
-  hp->no_alloc = true;
-  hp->scratch_refused = false;
-  const int st = gemm_backend<PolicyS>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c, ldc, 0, 1,
-                                       SBAMD_BATCH_STRIDED);
-  hp->no_alloc = false;
-  hp->scratch = saved;
-  hp->scratch_bytes = saved_bytes;
-  return st;
+  // The cube of this call is the device's fixed array; it travels with the call (the handle's own
+  // buffers are neither used nor touched, so other calls on the handle are not affected).
+  return gemm_backend<PolicyS>(h, transa, transb, m, n, k, alpha, a, lda, 0, b, ldb, 0, beta, c, ldc, 0, 1,
+                               SBAMD_BATCH_STRIDED, hp->fixed_scratch, SBAMD_NOALLOC_SCRATCH_BYTES);
 }
 
 int sbamd_dgemm(sbamd_handle_t h, char transa, char transb, int64_t m, int64_t n, int64_t k,

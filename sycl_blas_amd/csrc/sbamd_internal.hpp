@@ -45,12 +45,9 @@ struct Handle {
     hipEvent_t done;
   };
   std::vector<Retired> retired;
-  // Set for the duration of a call through the entry point that allocates
-  // nothing: `scratch` then points at this device's fixed array and a request
-  // beyond its size is refused instead of served by hipMalloc.
-  bool no_alloc = false;
-  bool scratch_refused = false;
-  void* fixed_scratch = nullptr;  // this device's address of the fixed array
+  // This device's address of the fixed array that the entry point which allocates
+  // nothing keeps its split-K cube in (looked up once, in sbamd_create).
+  void* fixed_scratch = nullptr;
   std::mutex mu;
   std::string last_error;
 };
@@ -116,6 +113,13 @@ struct Problem {
   int64_t batch;
   bool beta_zero;
   bool interleaved;  // batch index contiguous (gemm_batch_type_t::interleaved)
+  // Caller-provided split-K cube (the entry point that allocates nothing): when set, the
+  // partial products go there instead of the handle's on-demand buffer, the planner only
+  // considers cuts whose cube fits, and a pinned cut that does not fit fails with
+  // hipErrorOutOfMemory before anything is launched.  Carried per call, so other calls on
+  // the same handle are not affected.
+  void* cube = nullptr;
+  size_t cube_bytes = 0;
 };
 
 // Per-type back ends (defined in gemm_f32.hip, gemm_f64.hip, gemm_half.hip).

@@ -1,6 +1,7 @@
 """Randomised walk over the 16-bit GEMM paths (every storage pair, tile family pinned or automatic, ragged and
 vector-aligned shapes, K with and without tails, odd leading dimensions and offsets), each case checked like the
-16-bit parity tests.  Not collected by pytest; run by hand on a GPU box:  python tests/fuzz_half.py [seed] [cases]"""
+16-bit parity tests.  tests/test_fuzz_slices_gpu.py runs a fixed-seed slice under pytest; by hand on a GPU box the
+whole walk is  python tests/fuzz_half.py [seed] [cases]"""
 import os
 import sys
 
@@ -13,11 +14,10 @@ from sycl_blas_amd import _lib  # noqa: E402
 
 from test_gemm_half_gpu import PAIRS, run_case  # noqa: E402
 
-seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-rng = np.random.default_rng(seed)
-seen = {}
-with sb.SB_Handle(0) as h:
+
+def walk_half(h, rng, cases, log=None):
+    """Returns {family that ran: count}."""
+    seen = {}
     for i in range(cases):
         pair = PAIRS[int(rng.integers(0, len(PAIRS)))]
         m = int(rng.integers(1, 80)) * 8 if rng.integers(0, 4) else int(rng.integers(1, 600))
@@ -36,6 +36,19 @@ with sb.SB_Handle(0) as h:
         run_case(h, pair, m, n, k, ta, tb, alpha, beta, ldm=ldm, offset=offset, batch=batch, family=family, param=param)
         ran = h.last_kernel()
         seen[ran] = seen.get(ran, 0) + 1
-        if (i + 1) % 50 == 0:
-            print(f"{i + 1} cases ok; kernels that ran: {dict(sorted(seen.items()))}", flush=True)
-print("fuzz_half ok", seed, cases)
+        if log and (i + 1) % 50 == 0:
+            log(f"{i + 1} cases ok; kernels that ran: {dict(sorted(seen.items()))}")
+    return seen
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    rng = np.random.default_rng(seed)
+    with sb.SB_Handle(0) as h:
+        walk_half(h, rng, cases, lambda line: print(line, flush=True))
+    print("fuzz_half ok", seed, cases)
+
+
+if __name__ == "__main__":
+    main()

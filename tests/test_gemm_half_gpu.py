@@ -280,3 +280,37 @@ def test_unaligned_operands_of_big_products(sb_handle, pair):
         if m >= 1000:  # enough 64 x 64 tiles for the 128 x 128 direct-to-LDS tile to be the cheaper choice
             assert h.last_kernel() in (_lib.KERNEL_HUGE, _lib.KERNEL_LARGE)
         run_case(h, pair, m, n, k, ta, tb, -1.0, 0.0, ldm=2, offset=0, family=_lib.KERNEL_AUTO, param=1)
+
+
+def test_hgemm_against_the_reference_half_arithmetic(sb_handle):
+    """half -> half: the reference accumulates in binary16 (sycl::mad(half, half, half),
+    src/operations/blas3/gemm_common.hpp:45-51) where this library accumulates in float and rounds once -- a
+    deliberate difference (better numerics, different bits).  Both must satisfy what the reference's own test asks
+    of that pair: the HALF predicate (common/include/common/float_comparison.hpp:123-158).  Checked on the
+    reference's grids (blas3_gemm_test.cpp:29-84, :124-141 a slice) against the reference's binary16 chain in both of
+    its forms AND against the long-double result."""
+    h = sb_handle
+    cases = [(m, n, k) for m, n, k in itertools.product([11, 16, 32], [11, 32], [16, 17])] + [(253, 257, 511), (1024, 257, 253)]
+    for (m, n, k), ta, tb, (alpha, beta) in itertools.product(cases, "nt", "nt", [(1.5, 1.5), (1.5, 0.0)]):
+        rng = seeded("half-arith", m, n, k, ta, tb, alpha, beta)
+        lda, ldb = (k if ta == "t" else m), (n if tb == "t" else k)
+        a_h = rng.uniform(-2.0, 5.0, m * k).astype(np.float16)
+        b_h = rng.uniform(-2.0, 5.0, k * n).astype(np.float16)
+        c_h = rng.uniform(-2.0, 5.0, m * n).astype(np.float16)
+        a_g, b_g, c_g = (helper.allocate(h, "float16", x.size) for x in (a_h, b_h, c_h))
+        deps = [helper.copy_to_device(h, x.view(np.uint16), g) for x, g in ((a_h, a_g), (b_h, b_g), (c_h, c_g))]
+        h.wait(sb._gemm(h, ta, tb, m, n, k, alpha, a_g, lda, b_g, ldb, beta, c_g, m, deps))
+        got = np.empty(m * n, np.uint16)
+        h.wait(helper.copy_to_host(h, c_g, got))
+        for buf in (a_g, b_g, c_g):
+            helper.deallocate(buf)
+        got = got.view(np.float16).astype(np.float64)
+        what = f"half->half {m}x{n}x{k} {ta}{tb} a={alpha} b={beta}"
+        truth, _ = oracle.gemm_truth(ta == "t", tb == "t", m, n, k, alpha, a_h.astype(np.float64), lda,
+                                     b_h.astype(np.float64), ldb, beta, c_h.astype(np.float64), m)
+        assert oracle.compare_vectors(got, truth.astype(np.float16).astype(np.float64), "float16") == -1, what + " vs truth"
+        for form in (oracle.FORM_LOCAL, oracle.FORM_REF):
+            chain = c_h.view(np.uint16).copy()
+            assert oracle.gemm_half_chain(ta, tb, m, n, k, alpha, a_h.view(np.uint16), lda, b_h.view(np.uint16), ldb, beta,
+                                          chain, m, form=form) == 0
+            assert oracle.compare_vectors(got, oracle.half_to_double(chain), "float16") == -1, what + f" vs binary16 chain (form {form})"

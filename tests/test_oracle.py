@@ -210,3 +210,77 @@ def test_default_backend_tile_kernel_equals_the_local_form():
     ones = np.ones(16 * 16, np.float32)
     oracle.gemm_default_tile("n", "n", 16, 16, 16, 1.0, ones, 16, ones, 16, 0.0, c, 16)
     assert (c == 16).all()
+
+
+# ---- half -> half: the reference accumulates in binary16 (src/operations/blas3/gemm_common.hpp:45-51)
+
+
+def test_half_conversion_is_numpy_float16_rounding():
+    # numpy's float64 -> float16 conversion is correctly rounded; the oracle's own conversion must agree on
+    # normals, subnormals, ties (and near-ties), overflow and the special values
+    rng = np.random.default_rng(11)
+    h = rng.integers(0, 0x7BFF, 50000).astype(np.uint16)
+    lo = h.view(np.float16).astype(np.float64)
+    hi = (h + 1).astype(np.uint16).view(np.float16).astype(np.float64)
+    mid = (lo + hi) / 2
+    x = np.concatenate([rng.uniform(-70000, 70000, 100000), rng.uniform(-1e-4, 1e-4, 100000), rng.uniform(-1e-7, 1e-7, 50000),
+                        mid, mid * (1 + 1e-15), mid * (1 - 1e-15), -mid,
+                        [0.0, -0.0, np.inf, -np.inf, 65504, 65519.99, 65520, 65536, 2.0 ** -24, 2.0 ** -25, 3 * 2.0 ** -25, 1e-320]])
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(oracle.half_from_double(x), want)
+    every = np.arange(65536, dtype=np.uint16)
+    assert np.array_equal(oracle.half_to_double(every), every.view(np.float16).astype(np.float64), equal_nan=True)
+    assert np.isnan(oracle.half_to_double(oracle.half_from_double(np.array([np.nan])))).all()
+
+
+def _half_inputs(rng, count):
+    h = rng.uniform(-2.0, 5.0, count).astype(np.float16)
+    return h.view(np.uint16).copy(), h.astype(np.float64)
+
+
+def test_half_chain_equals_a_step_by_step_float16_loop():
+    # the same chain written with numpy float16 scalars: every product-and-add formed in float64 (exact product,
+    # sum rounded once) and rounded to float16 by numpy
+    rng = np.random.default_rng(5)
+    m, n, k = 5, 4, 37
+    for form, ta, tb in itertools.product([oracle.FORM_REF, oracle.FORM_LOCAL], "nt", "nt"):
+        lda, ldb, ldc = (k if ta == "t" else m) + 1, (n if tb == "t" else k) + 2, m + 3
+        a_bits, a = _half_inputs(rng, lda * (m if ta == "t" else k))
+        b_bits, b = _half_inputs(rng, ldb * (k if tb == "t" else n))
+        c_bits, c = _half_inputs(rng, ldc * n)
+        alpha, beta = np.float16(1.5), np.float16(-0.75)
+        got = c_bits.copy()
+        assert oracle.gemm_half_chain(ta, tb, m, n, k, alpha, a_bits, lda, b_bits, ldb, beta, got, ldc, form=form) == 0
+        want = c_bits.view(np.float16).copy()
+        f16, f64 = np.float16, np.float64
+        for j, i in itertools.product(range(n), range(m)):
+            acc = f16(0)
+            if form == oracle.FORM_LOCAL:
+                acc = f16(f64(f16(f64(beta) / f64(alpha))) * c[i + j * ldc])
+            for l in range(k):
+                av = a[l + i * lda] if ta == "t" else a[i + l * lda]
+                bv = b[j + l * ldb] if tb == "t" else b[l + j * ldb]
+                acc = f16(av * bv + f64(acc))
+            out = f16(f64(alpha) * f64(acc))
+            if form == oracle.FORM_REF:
+                out = f16(f64(out) + f64(f16(f64(beta) * c[i + j * ldc])))
+            want[i + j * ldc] = out
+        assert np.array_equal(got, want.view(np.uint16)), (form, ta, tb)
+
+
+def test_half_chain_passes_the_reference_half_predicate():
+    # What the reference's own half -> half test checks (test/unittest/blas3/blas3_gemm_common.hpp:147-152, :217-225
+    # with the half margins of float_comparison.hpp:123-158): its binary16 chain against a float GEMM of the same
+    # values.  Reference grids blas3_gemm_test.cpp:29-84 and :124-141 (a slice).
+    for (m, n, k), ta, tb in itertools.product([(11, 16, 17), (32, 11, 16), (253, 257, 511), (64, 33, 253)], "nt", "nt"):
+        rng = seeded("half-chain", m, n, k, ta, tb)
+        lda, ldb = (k if ta == "t" else m), (n if tb == "t" else k)
+        a_bits, a = _half_inputs(rng, m * k)
+        b_bits, b = _half_inputs(rng, k * n)
+        c_bits, c = _half_inputs(rng, m * n)
+        truth, _ = oracle.gemm_truth(ta == "t", tb == "t", m, n, k, 1.5, a, lda, b, ldb, 1.5, c, m)
+        for form, fused in itertools.product([oracle.FORM_REF, oracle.FORM_LOCAL], [True, False]):
+            got = c_bits.copy()
+            assert oracle.gemm_half_chain(ta, tb, m, n, k, 1.5, a_bits, lda, b_bits, ldb, 1.5, got, m, form=form, fused=fused) == 0
+            assert oracle.compare_vectors(oracle.half_to_double(got), truth.astype(np.float16).astype(np.float64), "float16") == -1
