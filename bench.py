@@ -13,11 +13,14 @@ N = 1: the workload is BASELINE config #2, SGEMM 8192 x 8192 x 8192 NN.
 N > 1: one process per GPU (launched by torch.distributed.run), operands resident on
 every GPU.
   --mode strong (default) the job is ONE 8192^3 GEMM whose full column-major C ends up
-                on every GPU, inside the timed region: the columns of C are dealt to
-                the ranks band by band, each rank multiplies straight into its slot
-                of the full C, and band b's RCCL all-gather (in place, no re-layout)
-                runs on a second stream while band b + 1 is being multiplied
-                (sycl_blas_amd.distributed.gathered_gemm).  --bands overrides the
+                on every GPU, inside the timed region, through the native multi-GPU
+                layer (include/sbamd_dist.h, sbamd_dist_gathered_{s,d}gemm): the columns
+                of C are dealt to the ranks, each rank multiplies its columns band by
+                band straight into their place, and a finished band goes directly into
+                the memory of every peer over the xGMI mesh (a copy kernel on a second
+                stream, ordered by flag words) while the next band is multiplied.
+                --transport rccl uses in-place ncclAllGather per band instead, --transport
+                torch the same schedule over torch.distributed.  --bands overrides the
                 number of bands, --no-gather leaves C distributed.
   --mode weak   every rank multiplies a full 8192^3 block of a (Pr*8192) x (Pc*8192) x 8192
                 job (2-D C blocks, no exchange at all); also reported as an extra of
@@ -55,14 +58,19 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="strong mode: leave C distributed (no collective)")
     ap.add_argument("--gather", action="store_true", help="accepted for compatibility: gathering is the default")
     ap.add_argument("--bands", type=int, default=0, help="column bands of the overlapped gather (0 = choose)")
+    ap.add_argument("--transport", choices=["auto", "mesh", "rccl", "torch"], default="auto",
+                    help="how a finished band reaches the peers: direct stores over the xGMI mesh (auto: tried first), "
+                         "RCCL all-gathers from the native layer, or torch.distributed collectives")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--one-rank-rccl", action="store_true",
-                    help="one process, one GPU, but through the N>1 code path with a one-rank RCCL group: checks that RCCL "
-                         "takes the in-place band gathers, streams and events as the multi-GPU run issues them (not a measurement)")
+                    help="one process, one GPU, but through the N>1 code path of the native layer on a one-rank RCCL "
+                         "communicator: the in-place band gathers are issued from the second stream behind events exactly "
+                         "as the multi-GPU run issues them (not a measurement)")
     ap.add_argument("--rehearse", action="store_true",
-                    help="rank logic check on a box with fewer GPUs than ranks: every rank uses GPU 0 and the barrier / "
-                         "max-over-ranks go through gloo; the number it prints is not a multi-GPU measurement")
+                    help="rank logic check on a box with fewer GPUs than ranks: every rank uses GPU 0 (the mesh transport "
+                         "then maps the peers' buffers of the same GPU through HIP IPC), the barrier / max-over-ranks go "
+                         "through gloo; the number it prints is not a multi-GPU measurement")
     return ap.parse_args()
 
 
@@ -360,10 +368,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import sycl_blas_amd as sb
-    from sycl_blas_amd.distributed import TorchStreams, block_of, gathered_gemm, grid_for, pick_bands
+    from sycl_blas_amd import _lib
+    from sycl_blas_amd.distributed import (Communicator, DistError, TorchStreams, band_widths, block_of, gathered_gemm, grid_for,
+                                           pick_bands, split_range, torch_allgather)
 
     # Everything of this rank -- allocations, fills, GEMMs -- is ordered on ONE explicit stream that
-    # torch and the library's handle share; collectives are launched from a second stream behind events.
+    # torch and the library's handle share; the traffic runs on a second stream behind events.
     compute = torch.cuda.Stream()
     torch.cuda.set_stream(compute)
     handle = sb.SB_Handle(local, compute.cuda_stream)
@@ -372,37 +382,94 @@ def main():
     pr, pc = grid_for(world)
     strong = dist_on and args.mode == "strong"
     gather = strong and not args.no_gather
-    comm = StagedGather(dist, torch) if args.rehearse else dist
+    staged = StagedGather(dist, torch) if args.rehearse else dist
     extras = {}
+    native, window, transport = None, -1, "none"
 
     if strong:
         # ONE size^3 product; A, B (replicated, same seeds everywhere) and the full C live on every rank.
         gm = gn = gk = size
         ops = Operands(torch, sb, handle, args.dtype, ta, tb, gm, gn, gk, 12345)
-        bands = args.bands or pick_bands(world, gm, gn, gk)
-        if gn % (bands * world):
-            raise SystemExit(f"--size must be divisible by bands * ranks = {bands * world}")
-        streams = TorchStreams(torch, compute)
         gemm_calls = []
 
         def local_gemm(tra, trb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
             gemm_calls.append((m, n, k))
             sb._gemm(handle, tra, trb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc)
 
-        def own_columns_only():
-            # this rank's band multiplications with no collective behind them
+        # Transport: the native layer's mesh first, its RCCL route second, torch.distributed last.  Every rank
+        # must end up with the same choice, so a rank that fails says so to all.
+        def agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if args.rehearse else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        want = args.transport
+        if args.one_rank_rccl:
+            want = "rccl"
+            os.environ["SBAMD_DIST_PREFER"] = "rccl"
+        if gather and want in ("auto", "mesh"):
+            try:
+                flags = _lib.DIST_MESH if args.rehearse else (_lib.DIST_MESH | _lib.DIST_RCCL)
+                native = Communicator(handle, rank, world, torch_allgather(dist), flags)
+                window = native.register(ops.c)
+                ok = True
+            except DistError as exc:
+                ok, extras["mesh_setup_error"] = False, str(exc)
+            if agree(ok):
+                transport = "mesh"
+            else:
+                if native is not None:
+                    native.close()
+                native, window = None, -1
+        if gather and native is None and want in ("auto", "rccl") and not args.rehearse:
+            try:
+                if want == "rccl":
+                    os.environ["SBAMD_DIST_PREFER"] = "rccl"
+                native = Communicator(handle, rank, world, torch_allgather(dist), _lib.DIST_RCCL)
+                ok = True
+            except DistError as exc:
+                ok, extras["rccl_setup_error"] = False, str(exc)
+            if agree(ok):
+                transport = "rccl"
+            else:
+                if native is not None:
+                    native.close()
+                native = None
+        if gather and native is None:
+            transport = "torch"
+
+        if transport == "mesh":
+            # rank r owns the columns split_range(gn, world, r), multiplied in bands that shrink towards the end
+            my0, my1 = split_range(gn, world, rank)
+            widths = band_widths(my1 - my0, args.bands, world)
+            bands = len(widths)
+            my_cols = []
+            for w in widths:
+                my_cols.append((my0, my0 + w))
+                my0 += w
+        else:
+            bands = args.bands or pick_bands(world, gm, gn, gk)
+            if gn % (bands * world):
+                raise SystemExit(f"--size must be divisible by bands * ranks = {bands * world}")
             w = gn // bands // world
-            for bi in range(bands):
-                col = bi * (gn // bands) + rank * w
-                local_gemm(ta, tb, gm, w, gk, 1.0, ops.a, ops.lda, ops.b + (col * ops.ldb if tb == "n" else col), ops.ldb, 0.0,
-                           ops.c + col * gm, gm)
+            my_cols = [(bi * (gn // bands) + rank * w, bi * (gn // bands) + (rank + 1) * w) for bi in range(bands)]
+        streams = TorchStreams(torch, compute)
+
+        def own_columns_only():
+            # this rank's band multiplications with nothing travelling behind them
+            for c0, c1 in my_cols:
+                local_gemm(ta, tb, gm, c1 - c0, gk, 1.0, ops.a, ops.lda, ops.b + (c0 * ops.ldb if tb == "n" else c0), ops.ldb, 0.0,
+                           ops.c + c0 * gm, gm)
 
         def step():
-            if gather:
-                gathered_gemm(comm, local_gemm, rank, world, ta, tb, gm, gn, gk, 1.0, ops.a, ops.lda, ops.b, ops.ldb, 0.0,
-                              ops.c, ops.tc_t, bands=bands, streams=streams)
-            else:
+            if not gather:
                 own_columns_only()
+            elif native is not None:
+                native.gathered_gemm(ta, tb, gm, gn, gk, 1.0, ops.a, ops.lda, ops.b, ops.ldb, 0.0, ops.c, gm, window,
+                                     args.bands if transport == "mesh" else bands)
+            else:
+                gathered_gemm(staged, local_gemm, rank, world, ta, tb, gm, gn, gk, 1.0, ops.a, ops.lda, ops.b, ops.ldb, 0.0,
+                              ops.c, ops.tc_t, bands=bands, streams=streams)
 
         bm, bn = gm, gn // world
     else:
@@ -433,16 +500,23 @@ def main():
         kernel_ms = device_time_ms(sb, handle, own_columns_only, max(3, args.steps // 2))
         extras["strong"] = {"bands": bands, "band_gemm_shapes": shapes, "gemm_only_ms_per_step": round(kernel_ms, 4),
                             "gather": gather}
+        if native is not None:
+            native.status()  # raises if a rank ever waited for a peer in vain
+            extras["strong"]["transport"] = transport
+            extras["strong"]["band_columns_of_rank0"] = [list(c) for c in my_cols]
         if gather:
-            # the gather alone (all bands back to back, nothing to hide behind)
+            # the traffic alone (this rank's whole column panel at once, nothing to hide behind)
             def gather_only():
+                if transport == "mesh":
+                    native.all_gather_c(1, world, gm, gn, ops.c, gm, window)
+                    return
                 works = []
                 width = gn // bands
                 for bi in range(bands):
                     col = bi * width + rank * (width // world)
                     out = ops.tc_t[bi * width * gm:(bi + 1) * width * gm]
-                    works.append(comm.all_gather_into_tensor(out, ops.tc_t[col * gm:(col + width // world) * gm],
-                                                             async_op=True))
+                    works.append(staged.all_gather_into_tensor(out, ops.tc_t[col * gm:(col + width // world) * gm],
+                                                               async_op=True))
                 for wk in works:
                     if wk is not None:
                         wk.wait()
@@ -454,6 +528,8 @@ def main():
             # of it (same kernel, same shape: bit for bit)
             step()
             torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
             digest = ops.tc_t.view(torch.int32 if args.dtype == "f32" else torch.int64).sum(dtype=torch.int64).reshape(1)
             lo, hi = digest.clone(), digest.clone()
             if args.rehearse:
@@ -461,14 +537,20 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             peer = (rank + 1) % world
-            w = gn // bands // world
-            col = peer * w  # the peer's part of band 0
+            if transport == "mesh":
+                col = split_range(gn, world, peer)[0]  # the peer's first band
+                w = band_widths(split_range(gn, world, peer)[1] - col, args.bands, world)[0]
+            else:
+                w = gn // bands // world
+                col = peer * w  # the peer's part of band 0
             theirs = ops.tc_t[col * gm:(col + w) * gm].clone()
             sb._gemm(handle, ta, tb, gm, w, gk, 1.0, ops.a, ops.lda, ops.b + (col * ops.ldb if tb == "n" else col), ops.ldb, 0.0,
                      ops.c + col * gm, gm)
             torch.cuda.synchronize()
             extras["strong"]["gathered_c_identical_on_all_ranks"] = bool(lo.item() == hi.item())
             extras["strong"]["peer_part_equals_local_recompute"] = bool(torch.equal(theirs, ops.tc_t[col * gm:(col + w) * gm]))
+            if dist_on:
+                dist.barrier()  # nobody starts the next collective while a peer still recomputes into its C
         # weak scaling, reported beside the headline, never as `value`
         wops = Operands(torch, sb, handle, args.dtype, ta, tb, size, size, size, 999 + rank)
         for _ in range(3):
@@ -488,7 +570,7 @@ def main():
         if strong:
             workload = (f"{sd.upper()}GEMM {size}x{size}x{size} {args.trans.upper()} cut over {world} GPUs (columns of C dealt in {bands} "
                         f"band(s)), alpha=1 beta=0, through sbamd_{sd}gemm" +
-                        (", full C gathered on every GPU inside the timed region (RCCL all-gather per band, overlapped)" if gather
+                        (f", full C gathered on every GPU inside the timed region (transport: {transport}, overlapped)" if gather
                          else ", C left distributed"))
         else:
             workload = (f"{sd.upper()}GEMM {size}x{size}x{size} {args.trans.upper()} per GPU C-block, alpha=1 beta=0, "
@@ -509,7 +591,8 @@ def main():
             "config": {
                 "workload": workload,
                 "job": f"{gm}x{gn}x{gk}",
-                "grid": f"1x{world} column bands" if strong else f"{pr}x{pc} C blocks",
+                "grid": f"1x{world} column panels" if strong else f"{pr}x{pc} C blocks",
+                "transport": transport if strong else "none",
                 "gather": bool(gather),
                 "pct_of_mfma_peak_per_gpu": round(100.0 * value / world / peak, 2),
             },
@@ -525,9 +608,9 @@ def main():
             },
         }
         if args.rehearse:
-            out["config"]["rehearsal"] = "all ranks on GPU 0, collectives staged through the host: NOT a multi-GPU measurement"
+            out["config"]["rehearsal"] = "all ranks on GPU 0 (peers mapped through HIP IPC on one device): NOT a multi-GPU measurement"
         if args.one_rank_rccl:
-            out["config"]["rehearsal"] = "the N>1 code path on a one-rank RCCL group: NOT a multi-GPU measurement"
+            out["config"]["rehearsal"] = "the N>1 code path of the native layer on a one-rank RCCL communicator: NOT a multi-GPU measurement"
         if extras:
             out["extras"] = extras
 
@@ -558,6 +641,11 @@ def main():
                                        "sample": f"failed: {exc!r}"}
         print(json.dumps(out), flush=True)
 
+    if native is not None:
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        native.close()
     handle.close()
     if dist_on:
         dist.destroy_process_group()

@@ -1,4 +1,4 @@
-"""ctypes binding of libsbamd.so (the C ABI declared in include/sbamd_gemm.h).
+"""ctypes binding of libsbamd.so (the C ABI declared in include/sbamd_gemm.h and include/sbamd_dist.h).
 
 The library is loaded from the source tree (sycl_blas_amd/lib/libsbamd.so, built
 by sycl_blas_amd/csrc/Makefile).  There is no fallback: if the shared object is
@@ -18,6 +18,9 @@ INVALID_HANDLE, INVALID_VALUE, HIP_ERROR, ALLOC_FAILED, NOT_SUPPORTED = 6, 7, 8,
 INVALID_UPLO, INVALID_SIDE = 11, 12
 TRSM_INVALID_SIZE, TRSM_INVALID_SIDE, TRSM_INVALID_UPLO, TRSM_INVALID_TRANS, TRSM_INVALID_DIAG = 13, 14, 15, 16, 17
 SCRATCH_TOO_SMALL = 18
+RCCL_ERROR, DIST_TIMEOUT, DIST_BOOTSTRAP, DIST_NO_TRANSPORT = 19, 20, 21, 22
+DIST_MESH, DIST_RCCL = 1, 2
+DIST_MAX_RANKS, DIST_MAX_BANDS = 16, 16
 NOALLOC_SCRATCH_BYTES = 64 << 20
 BATCH_STRIDED, BATCH_INTERLEAVED = 0, 1
 KERNEL_AUTO, KERNEL_LARGE, KERNEL_SMALL, KERNEL_SPLITK, KERNEL_NAIVE, KERNEL_HUGE = 0, 1, 2, 3, 4, 5
@@ -89,6 +92,37 @@ for _p, _sc in (("s", _f32), ("d", _f64)):
     SIGNATURES[f"sbamd_{_p}symm"] = (_int, [_vp, _ch, _ch, _i64, _i64, _sc, _vp, _i64, _vp, _i64, _sc, _vp, _i64])
     SIGNATURES[f"sbamd_{_p}trsm"] = (_int, [_vp, _ch, _ch, _ch, _ch, _i64, _i64, _sc, _vp, _i64, _vp, _i64])
 
+# ---- the multi-GPU layer (include/sbamd_dist.h)
+ALLGATHER_FN = C.CFUNCTYPE(_int, _vp, _vp, _vp, C.c_size_t)
+_pi64 = C.POINTER(_i64)
+
+
+def _dist_gemm_sig(scalar):
+    return [_vp, _ch, _ch, _i64, _i64, _i64, scalar, _vp, _i64, _vp, _i64, scalar, _vp, _i64]
+
+
+DIST_SIGNATURES = {
+    "sbamd_dist_create": (_int, [C.POINTER(_vp), _vp, _int, _int, ALLGATHER_FN, _vp, _int, C.c_size_t]),
+    "sbamd_dist_destroy": (_int, [_vp]),
+    "sbamd_dist_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
+    "sbamd_dist_register": (_int, [_vp, _vp, C.c_size_t, C.POINTER(_int)]),
+    "sbamd_dist_unregister": (_int, [_vp, _int]),
+    "sbamd_dist_barrier": (_int, [_vp]),
+    "sbamd_dist_status": (_int, [_vp]),
+    "sbamd_dist_grid": (None, [_int, C.POINTER(_int), C.POINTER(_int)]),
+    "sbamd_dist_split_range": (None, [_i64, _int, _int, _pi64, _pi64]),
+    "sbamd_dist_block_of": (_int, [_int, _int, _int, _i64, _i64, _pi64, _pi64, _pi64, _pi64]),
+    "sbamd_dist_band_widths": (_int, [_i64, _int, _int, _pi64]),
+    "sbamd_dist_all_gather_c": (_int, [_vp, _int, _int, _i64, _i64, _vp, _i64, _int, _int]),
+    "sbamd_dist_last_bands": (_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
+}
+for _p, _sc in (("s", _f32), ("d", _f64), ("bs", _f32)):
+    SIGNATURES_BLOCK = [_vp, _int, _int, _ch, _ch, _i64, _i64, _i64, _sc, _vp, _i64, _vp, _i64, _sc, _vp, _i64]
+    DIST_SIGNATURES[f"sbamd_dist_block_{_p}gemm"] = (_int, SIGNATURES_BLOCK)
+for _p, _sc in (("s", _f32), ("d", _f64)):
+    DIST_SIGNATURES[f"sbamd_dist_gathered_{_p}gemm"] = (_int, _dist_gemm_sig(_sc) + [_int, _int])
+    DIST_SIGNATURES[f"sbamd_dist_splitk_{_p}gemm"] = (_int, _dist_gemm_sig(_sc) + [_int, _int])
+
 _lib = None
 
 
@@ -103,7 +137,7 @@ def load():
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "There is no CPU fallback for the GEMM path.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DIST_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args

@@ -5,42 +5,47 @@ include/sb_handle/portblas_handle.h:46-60), so this layer is new.  GEMM shards
 naturally: C blocks are independent.  One process drives one GPU; the ranks form
 a Pr x Pc grid, rank (i, j) owns C block (i, j) and needs only the A row-panel i
 and the B column-panel j, so with the panels resident the block products need NO
-exchange.  Collectives (RCCL through torch.distributed) appear only where data
-really moves:
+exchange.  Data moves only where an output has to be assembled.
 
-  * all_gather_c      -- assemble the full C on every rank (optional);
-  * gathered_gemm     -- the strong-scaling schedule for a C that every rank needs whole:
-                         columns are dealt to the ranks band by band, each rank
-                         multiplies straight into its slot of the full column-major
-                         C, and band b's all-gather (in place, no re-layout) runs
-                         while band b + 1 is being multiplied;
-  * splitk_gemm       -- K is cut across ranks instead, every rank produces a
-                         full-size partial C, and a reduce-scatter sums them and
-                         leaves each rank one column slab of the result.
+The product path is native: `Communicator` binds the C ABI of include/sbamd_dist.h
+(sycl_blas_amd/csrc/sbamd_dist.hip) -- C blocks, the strong-scaling schedule with
+the whole C on every rank, the K cut across ranks -- over two transports: direct
+stores into the peers' memory across the xGMI mesh (buffers exchanged once as HIP
+IPC handles) and RCCL collectives.  The partition arithmetic below calls the same
+C functions, so there is one implementation of it.
 
-Every function takes the local GEMM as a callable, so the partition and the
-collectives can be exercised on CPU ranks (gloo) without the HIP library.
+The functions further down that take a `dist` module and a `local_gemm` callable
+(all_gather_c, gathered_gemm, splitk_gemm) are the same schedules over
+torch.distributed; they exist so that the rank logic can be exercised by CPU ranks
+over gloo, without a GPU.
 """
-import math
+import ctypes as C
+
+from . import _lib
 
 GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
 
 
 def grid_for(world):
-    """Process grid Pr x Pc (Pr <= Pc) for `world` ranks."""
-    if world in GRIDS:
-        return GRIDS[world]
-    pr = int(math.isqrt(world))
-    while world % pr:
-        pr -= 1
-    return pr, world // pr
+    """Process grid Pr x Pc (Pr <= Pc) for `world` ranks (sbamd_dist_grid)."""
+    pr, pc = C.c_int(), C.c_int()
+    _lib.load().sbamd_dist_grid(int(world), C.byref(pr), C.byref(pc))
+    return pr.value, pc.value
 
 
 def split_range(extent, parts, index):
-    """Balanced [begin, end) of piece `index` when `extent` is cut into `parts`."""
-    base, rem = divmod(extent, parts)
-    begin = index * base + min(index, rem)
-    return begin, begin + base + (1 if index < rem else 0)
+    """Balanced [begin, end) of piece `index` when `extent` is cut into `parts` (sbamd_dist_split_range)."""
+    b, e = C.c_int64(), C.c_int64()
+    _lib.load().sbamd_dist_split_range(int(extent), int(parts), int(index), C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+def band_widths(cols, bands, world):
+    """Widths of the column bands one rank's `cols` columns are multiplied in by Communicator.gathered_gemm
+    (sbamd_dist_band_widths): `bands` equal parts, or for bands == 0 halves that shrink towards the end."""
+    out = (C.c_int64 * _lib.DIST_MAX_BANDS)()
+    count = _lib.load().sbamd_dist_band_widths(int(cols), int(bands), int(world), out)
+    return [out[i] for i in range(count)]
 
 
 def coords_of(rank, pr, pc):
@@ -51,9 +56,12 @@ def coords_of(rank, pr, pc):
 
 
 def block_of(rank, pr, pc, m, n):
-    """((row_begin, row_end), (col_begin, col_end)) of the C block a rank owns."""
-    i, j = coords_of(rank, pr, pc)
-    return split_range(m, pr, i), split_range(n, pc, j)
+    """((row_begin, row_end), (col_begin, col_end)) of the C block a rank owns (sbamd_dist_block_of)."""
+    r0, r1, c0, c1 = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    if _lib.load().sbamd_dist_block_of(int(rank), int(pr), int(pc), int(m), int(n), C.byref(r0), C.byref(r1), C.byref(c0),
+                                       C.byref(c1)) != _lib.OK:
+        raise ValueError("rank outside the process grid")
+    return (r0.value, r1.value), (c0.value, c1.value)
 
 
 def panel_offsets(rank, pr, pc, transa, transb, m, n, lda, ldb):
@@ -245,7 +253,7 @@ def gathered_gemm(dist, local_gemm, rank, world, transa, transb, m, n, k, alpha,
         b_off = c0 * ldb if transb.lower() == "n" else c0
         local_gemm(transa, transb, m, c1 - c0, k, alpha, a, lda, b + b_off, ldb, beta, c + c0 * m, m)
         done = streams.gemm_done()
-        if world == 1:
+        if dist is None:  # no process group at all; a one-rank group still issues its collectives
             continue
         out = c_tensor[bi * width * m:(bi + 1) * width * m]
         mine = c_tensor[c0 * m:c1 * m]
@@ -253,3 +261,137 @@ def gathered_gemm(dist, local_gemm, rank, world, transa, transb, m, n, k, alpha,
             works.append(dist.all_gather_into_tensor(out, mine if in_place else mine.clone(), group=group, async_op=True))
     streams.finish(works)
     return cols
+
+
+# ----------------------------------------------------------------- the native layer
+
+
+class DistError(RuntimeError):
+    """A failure reported by the native multi-GPU layer (HIP, RCCL, a peer that never arrived)."""
+
+
+def torch_allgather(dist, group=None):
+    """Out-of-band exchange for Communicator over a torch.distributed process group (any back end)."""
+    def exchange(payload):
+        world = dist.get_world_size(group)
+        out = [None] * world
+        dist.all_gather_object(out, payload, group=group)
+        return out
+    return exchange
+
+
+class Communicator:
+    """sbamd_comm_t: the ranks of one node, one process per GPU (include/sbamd_dist.h).
+
+    handle     the rank's SB_Handle (its device and stream; must outlive the communicator)
+    allgather  callable(bytes) -> list of every rank's bytes in rank order: the out-of-band exchange used
+               while the communicator and its windows are set up (torch_allgather(dist) makes one)
+    transports _lib.DIST_MESH | _lib.DIST_RCCL
+    Every method is collective: all ranks call it, same arguments apart from pointers, same order.
+    """
+
+    _SUFFIX = {"float32": "s", "float64": "d"}
+
+    def __init__(self, handle, rank, world, allgather=None, transports=_lib.DIST_MESH, workspace_bytes=0):
+        self._c = None
+        self.handle, self.rank, self.world, self.transports = handle, int(rank), int(world), int(transports)
+        self._exchange = allgather
+        self._failure = None
+
+        def callback(_ctx, send, recv, nbytes):
+            try:
+                parts = self._exchange(C.string_at(send, nbytes))
+                if len(parts) != self.world or any(len(p) != nbytes for p in parts):
+                    raise ValueError("the all-gather returned the wrong number or size of parts")
+                for i, part in enumerate(parts):
+                    C.memmove(recv + i * nbytes, part, nbytes)
+                return 0
+            except Exception as exc:  # never let an exception cross the C boundary
+                self._failure = exc
+                return 1
+
+        self._cb = _lib.ALLGATHER_FN(callback)  # kept alive with the object
+        raw = C.c_void_p()
+        st = _lib.load().sbamd_dist_create(C.byref(raw), handle._h, self.rank, self.world, self._cb, None, self.transports,
+                                           int(workspace_bytes))
+        self._check(st, "sbamd_dist_create")
+        self._c = raw
+
+    def _check(self, st, what):
+        if st == _lib.OK:
+            return
+        detail = _lib.load().sbamd_last_error(self.handle._h).decode() if self.handle._h else ""
+        if self._failure is not None:
+            detail += f" ({self._failure!r})"
+        raise DistError(f"{what}: {_lib.status_string(st)} [{st}] {detail}")
+
+    def close(self):
+        if self._c:
+            _lib.load().sbamd_dist_destroy(self._c)
+            self._c = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def register(self, buf, nbytes=None):
+        """Make a device buffer (DeviceBuffer or address) writable by every peer; returns the window id."""
+        ptr = getattr(buf, "ptr", buf)
+        if nbytes is None:
+            nbytes = buf.count * buf.itemsize
+        win = C.c_int(-1)
+        self._check(_lib.load().sbamd_dist_register(self._c, C.c_void_p(int(ptr)), int(nbytes), C.byref(win)), "sbamd_dist_register")
+        return win.value
+
+    def unregister(self, window):
+        self._check(_lib.load().sbamd_dist_unregister(self._c, int(window)), "sbamd_dist_unregister")
+
+    def barrier(self):
+        self._check(_lib.load().sbamd_dist_barrier(self._c), "sbamd_dist_barrier")
+
+    def status(self):
+        """Raises if a device-side wait of this communicator has timed out (synchronises the stream)."""
+        self._check(_lib.load().sbamd_dist_status(self._c), "sbamd_dist_status")
+
+    def block_gemm(self, pr, pc, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
+        """This rank's C block of the global product; a, b, c address the FULL operands.  No exchange."""
+        suffix = "bs" if a.dtype == "bfloat16" else self._SUFFIX[c.dtype]
+        sc = C.c_double if suffix == "d" else C.c_float
+        fn = getattr(_lib.load(), f"sbamd_dist_block_{suffix}gemm")
+        self._check(fn(self._c, int(pr), int(pc), transa.encode(), transb.encode(), m, n, k, sc(alpha), a.ptr, lda, b.ptr, ldb,
+                       sc(beta), c.ptr, ldc), "sbamd_dist_block_gemm")
+
+    def all_gather_c(self, pr, pc, m, n, c, ldc, window=-1):
+        """Assemble the full C on every rank from the Pr x Pc blocks, in place, nothing re-laid out on the host."""
+        self._check(_lib.load().sbamd_dist_all_gather_c(self._c, int(pr), int(pc), m, n, c.ptr, ldc, c.itemsize, int(window)),
+                    "sbamd_dist_all_gather_c")
+
+    def gathered_gemm(self, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, window=-1, bands=0):
+        """Strong scaling with the whole C on every rank (multiplication and traffic overlapped)."""
+        suffix = self._SUFFIX[c.dtype]
+        sc = C.c_double if suffix == "d" else C.c_float
+        fn = getattr(_lib.load(), f"sbamd_dist_gathered_{suffix}gemm")
+        self._check(fn(self._c, transa.encode(), transb.encode(), m, n, k, sc(alpha), a.ptr, lda, b.ptr, ldb, sc(beta), c.ptr, ldc,
+                       int(window), int(bands)), "sbamd_dist_gathered_gemm")
+
+    def splitk_gemm(self, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, window=-1, gather=False):
+        """K cut across the ranks; rank r ends with the columns split_range(n, world, r) (all of C with gather)."""
+        suffix = self._SUFFIX[c.dtype]
+        sc = C.c_double if suffix == "d" else C.c_float
+        fn = getattr(_lib.load(), f"sbamd_dist_splitk_{suffix}gemm")
+        self._check(fn(self._c, transa.encode(), transb.encode(), m, n, k, sc(alpha), a.ptr, lda, b.ptr, ldb, sc(beta), c.ptr, ldc,
+                       int(window), int(bool(gather))), "sbamd_dist_splitk_gemm")
+
+    def last_bands(self):
+        """[(col_begin, col_end, depth, k_chunk), ...]: this rank's multiplications in the last gathered call."""
+        arrays = [(C.c_int64 * _lib.DIST_MAX_BANDS)() for _ in range(4)]
+        count = _lib.load().sbamd_dist_last_bands(self._c, *arrays)
+        return [tuple(arr[i] for arr in arrays) for i in range(count)]

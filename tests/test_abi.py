@@ -1,5 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/sbamd_gemm.h declares
-(no compute calls: this runs without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/sbamd_gemm.h and include/sbamd_dist.h
+declare (no compute calls: this runs without a GPU)."""
 import ctypes
 import os
 import re
@@ -12,8 +12,8 @@ from sycl_blas_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "sbamd_gemm.h")).read()
+def declared_symbols(header="sbamd_gemm.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(sbamd_[a-z0-9_]+)\s*\(", text)))
 
@@ -25,6 +25,27 @@ def test_header_symbols_are_exported_and_bound():
     for name in names:
         assert hasattr(lib, name), f"{name} is declared in the header but not exported"
     assert sorted(_lib.SIGNATURES) == names, "Python prototypes and the header disagree"
+    dist = declared_symbols("sbamd_dist.h")
+    assert len(dist) >= 18
+    for name in dist:
+        assert hasattr(lib, name), f"{name} is declared in sbamd_dist.h but not exported"
+    assert sorted(_lib.DIST_SIGNATURES) == dist, "Python prototypes and sbamd_dist.h disagree"
+
+
+def test_partition_helpers_need_no_device():
+    # the C side of sycl_blas_amd.distributed's partition arithmetic (grid, balanced ranges, bands)
+    from sycl_blas_amd import distributed as d
+
+    assert [d.grid_for(w) for w in (1, 2, 4, 8, 6, 9)] == [(1, 1), (1, 2), (2, 2), (2, 4), (2, 3), (3, 3)]
+    assert [d.split_range(10, 4, i) for i in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert d.block_of(5, 2, 4, 65536, 65536) == ((32768, 65536), (16384, 32768))
+    # shrinking halves, multiples of 64, a small last band; one rank multiplies in one piece
+    assert d.band_widths(1024, 0, 8) == [512, 256, 128, 128]
+    assert d.band_widths(4096, 0, 2) == [2048, 1024, 512, 512]
+    assert d.band_widths(1000, 0, 4) == [512, 256, 232]
+    assert d.band_widths(1000, 3, 4) == [334, 333, 333]
+    assert d.band_widths(8192, 0, 1) == [8192]
+    assert d.band_widths(100, 0, 8) == [100]
 
 
 def test_status_strings_match_reference_messages():

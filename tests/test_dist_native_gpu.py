@@ -1,0 +1,66 @@
+"""The native multi-GPU layer (include/sbamd_dist.h) on a one-GPU box.
+
+The reference has no multi-device code, so there is no reference test to mirror; what is checked is that every
+schedule of the layer reproduces, bit for bit, what the single-GPU entry points (pinned against the oracle by the
+other tests) and the oracle itself give on the same inputs:
+  * samples/dist_gemm_sample: rank processes forked by the sample, bootstrapped through shared memory -- one
+    rank, several ranks sharing GPU 0 (HIP IPC mappings, flag words, peer stores, the rank-ordered sum all run
+    for real, only the links are missing), ragged sizes, and a one-rank RCCL communicator with RCCL preferred,
+    which issues every collective call of the RCCL route;
+  * tests/dist_worker.py: the Python binding (sycl_blas_amd.distributed.Communicator) under
+    torch.distributed.run with a gloo side channel, checked against the CPU oracle.
+A multi-GPU measurement needs a multi-GPU node; this file proves the logic, not the bandwidth."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAMPLE = os.path.join(ROOT, "samples", "dist_gemm_sample")
+
+
+def run(cmd, timeout=300, env=None):
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert proc.returncode == 0, f"{' '.join(cmd)} -> {proc.returncode}\n{proc.stdout[-2000:]}\n{proc.stderr[-4000:]}"
+    return proc.stdout
+
+
+@pytest.mark.parametrize("args", [
+    ["--ranks", "1"],
+    ["--ranks", "2", "--share-gpu"],
+    ["--ranks", "4", "--share-gpu", "--dtype", "double"],
+    ["--ranks", "3", "--share-gpu", "--m", "333", "--n", "1000", "--k", "777"],
+    ["--ranks", "8", "--share-gpu", "--m", "512", "--n", "2048", "--k", "300"],
+    ["--ranks", "1", "--prefer-rccl"],
+    ["--ranks", "1", "--prefer-rccl", "--dtype", "double", "--n", "3072"],
+], ids=lambda a: "_".join(x.strip("-") for x in a))
+def test_sample_self_checks(args):
+    assert os.path.exists(SAMPLE), "build the samples first (python -c 'import __graft_entry__ as g; g.build()')"
+    out = run([SAMPLE] + args)
+    assert "dist sample ok" in out
+
+
+@pytest.mark.parametrize("world,dtype", [(2, "float32"), (4, "float64")])
+def test_python_binding_against_the_oracle(world, dtype):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(29500 + 7 * world), os.path.join(ROOT, "tests", "dist_worker.py"), dtype], timeout=400, env=env)
+    assert "dist worker ok" in out
+
+
+def test_bench_rehearsal_runs_the_mesh_transport():
+    """bench.py's N > 1 path with two ranks on GPU 0: the native layer's mesh transport end to end, with the bench's
+    own assertions (every rank holds the same C; a peer's part equals this rank's recomputation of it)."""
+    import json
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--size", "2048", "--steps", "3",
+               "--warmup", "2"], timeout=400, env=env)
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    strong = line["extras"]["strong"]
+    assert line["config"]["transport"] == "mesh" and strong["transport"] == "mesh"
+    assert strong["gathered_c_identical_on_all_ranks"] and strong["peer_part_equals_local_recompute"]
