@@ -495,9 +495,8 @@ def main():
 
     # Device time of this rank's multiplications alone (HIP events on the stream the kernels run on).
     if strong:
-        shapes = list(dict.fromkeys(gemm_calls))
-
         kernel_ms = device_time_ms(sb, handle, own_columns_only, max(3, args.steps // 2))
+        shapes = list(dict.fromkeys(gemm_calls))
         extras["strong"] = {"bands": bands, "band_gemm_shapes": shapes, "gemm_only_ms_per_step": round(kernel_ms, 4),
                             "gather": gather}
         if native is not None:
