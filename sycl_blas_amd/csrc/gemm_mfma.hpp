@@ -20,7 +20,7 @@
 
 #include <type_traits>
 
-#include "gemm_f32_kloop.hpp"
+#include "gemm_kloop_asm.hpp"
 
 namespace sbamd {
 
@@ -50,8 +50,8 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef SBAMD_LAB_VARIANT
 #define SBAMD_LAB_VARIANT 1
 #endif
-// 1: interior tiles of the fp32 256 x 256 x 16 kernel run their steady-state K loop as the hand-scheduled
-// assembly block of gemm_f32_kloop.hpp; 0: the compiled loop everywhere (same bits either way).
+// 1: interior tiles of the tile shapes that have one run their steady-state K loop as the hand-scheduled
+// assembly block of gemm_kloop_asm.hpp; 0: the compiled loop everywhere (same bits either way).
 #ifndef SBAMD_KLOOP_ASM
 #define SBAMD_KLOOP_ASM 1
 #endif
@@ -628,31 +628,42 @@ struct GemmBody {
     }
   }
 
-  // The steady-state K loop in assembly (gemm_f32_kloop.hpp) for the fp32 256 x 256 x 16 tile.  Called with the
-  // state the compiled loop has at kt = 0 (tile 0 in buffer 0, tile 1 on its way into the staging registers,
-  // the pointers at tile 2, group 0 of tile 0 in fa[0] / fb[0]); runs an even number of K steps, leaves the same
-  // state for kt = that number and returns it (0: not taken).  Taken for tiles that lie wholly inside the
-  // matrices (the block addresses global memory as a scalar base plus a 32-bit per-lane offset, without the
-  // clamping of edge tiles) whose leading dimensions keep those offsets below 2^32.
-  static constexpr bool KLOOP_ASM = SBAMD_KLOOP_ASM && !SBAMD_ABLATE && std::is_same<T, float>::value &&
-                                    std::is_same<MS, Mfma<float>>::value && BM == 256 && BN == 256 && BK == 16 &&
-                                    K::MI == KLoopF32<TA, TB>::MI && K::NI == KLoopF32<TA, TB>::NI;
+  // The steady-state K loop in assembly (gemm_kloop_asm.hpp) for the tile shapes that have a block there.  Called
+  // with the state the compiled loop has at kt = 0 (tile 0 in buffer 0, tile 1 on its way into the staging
+  // registers, the pointers at tile 2, the first GA fragment groups of tile 0 in fa[0..GA) / fb[0..GA)); runs an
+  // even number of K steps, leaves the same state for kt = that number and returns it (0: not taken).  Taken
+  // for tiles that lie wholly inside the matrices (the block addresses global memory as a scalar base plus a
+  // 32-bit per-lane offset, without the clamping of edge tiles) whose leading dimensions keep those offsets
+  // below 2^32.
+  using KL = KLoop<T, BM, BN, BK, WM, WN, TA, TB>;
+  static constexpr bool KLOOP_ASM = SBAMD_KLOOP_ASM && !SBAMD_ABLATE && std::is_same<MS, Mfma<T>>::value && KL::available &&
+                                    KL::MI == K::MI && KL::NI == K::NI;
+  template <int NS>
   __device__ inline int run_kloop_asm(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0, int64_t k_begin,
-                                      int nfull, SBAMD_LDS T* smem, int tid, int a_mn, int b_mn, T (&fa0)[K::MI][M::GS],
-                                      T (&fb0)[K::NI][M::GS]) {
+                                      int nfull, SBAMD_LDS T* smem, int tid, int a_mn, int b_mn, T (&fa)[NS][K::MI][M::GS],
+                                      T (&fb)[NS][K::NI][M::GS]) {
     if constexpr (KLOOP_ASM) {
-      using KL = KLoopF32<TA, TB>;
       constexpr bool A_KM = TA, B_KM = !TB;
+      constexpr int ES = int(sizeof(T)), V = M::V, GS = M::GS;
+      static_assert(KL::NVA == LoadA::NV && KL::NVB == LoadB::NV && KL::GA <= NS, "the block was generated for this tile");
       const int iters = (nfull - 2) / 2;
-      if (iters < 1 || m0 + BM > g.m || n0 + BN > g.n || g.lda >= (int64_t(1) << 22) || g.ldb >= (int64_t(1) << 22)) return 0;
-      const int lk = (tid & 63) >> 5;
+      // largest per-lane byte offset inside a tile: (rows - 1) * ld + the last vector of a row
+      constexpr int64_t ROWS_A = int64_t(LoadA::NVEC) / LoadA::PER_ROW, ROWS_B = int64_t(LoadB::NVEC) / LoadB::PER_ROW;
+      const bool offsets_fit = ((ROWS_A - 1) * g.lda + LoadA::PER_ROW * V) * ES < (int64_t(1) << 32) &&
+                               ((ROWS_B - 1) * g.ldb + LoadB::PER_ROW * V) * ES < (int64_t(1) << 32);
+      if (iters < 1 || m0 + BM > g.m || n0 + BN > g.n || !offsets_fit) return 0;
+      const int lk = M::lane_k(tid & 63);
       const uint32_t lds0 = uint32_t(uintptr_t(smem));
-      uint32_t goa[2], gob[2];
+      uint32_t goa[KL::NVA], gob[KL::NVB];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < KL::NVA; ++i) {
         const int v = tid + i * K::NT;
-        goa[i] = A_KM ? uint32_t(((v % 4) * 4 + int64_t(v / 4) * g.lda) * 4) : uint32_t(((v % 64) * 4 + int64_t(v / 64) * g.lda) * 4);
-        gob[i] = B_KM ? uint32_t(((v % 4) * 4 + int64_t(v / 4) * g.ldb) * 4) : uint32_t(((v % 64) * 4 + int64_t(v / 64) * g.ldb) * 4);
+        goa[i] = uint32_t(((v % LoadA::PER_ROW) * V + int64_t(v / LoadA::PER_ROW) * g.lda) * ES);
+      }
+#pragma unroll
+      for (int i = 0; i < KL::NVB; ++i) {
+        const int v = tid + i * K::NT;
+        gob[i] = uint32_t(((v % LoadB::PER_ROW) * V + int64_t(v / LoadB::PER_ROW) * g.ldb) * ES);
       }
       const int64_t k2 = k_begin + 2 * BK;  // the pointers stand at tile 2
       // wave-uniform by construction; say so to the compiler (the block takes them in scalar registers)
@@ -663,38 +674,82 @@ struct GemmBody {
       };
       uint64_t base_a = uniform(uint64_t(uintptr_t(A_KM ? a + k2 + m0 * g.lda : a + m0 + k2 * g.lda)));
       uint64_t base_b = uniform(uint64_t(uintptr_t(B_KM ? b + k2 + n0 * g.ldb : b + n0 + k2 * g.ldb)));
-      const uint64_t step_a = uniform(A_KM ? uint64_t(BK * 4) : uint64_t(g.lda) * (BK * 4));
-      const uint64_t step_b = uniform(B_KM ? uint64_t(BK * 4) : uint64_t(g.ldb) * (BK * 4));
-      const uint32_t rda = lds0 + uint32_t(A_KM ? (a_mn * LoadA::S + 2 * lk) * 4 : (lk * LoadA::S + a_mn) * 4);
-      const uint32_t rdb = lds0 + uint32_t(K::A_ELEMS * 4) + uint32_t(B_KM ? (b_mn * LoadB::S + 2 * lk) * 4 : (lk * LoadB::S + b_mn) * 4);
-      const uint32_t wra = lds0 + uint32_t(A_KM ? ((tid / 4) * LoadA::S + (tid % 4) * 4) * 4 : ((tid / 64) * LoadA::S + (tid % 64) * 4) * 4);
-      const uint32_t wrb = lds0 + uint32_t(K::A_ELEMS * 4) +
-                           uint32_t(B_KM ? ((tid / 4) * LoadB::S + (tid % 4) * 4) * 4 : ((tid / 64) * LoadB::S + (tid % 64) * 4) * 4);
-      f32x4 sta[2], stb[2];
-      typename KL::fa_t fav;
-      typename KL::fb_t fbv;
+      const uint64_t step_a = uniform(A_KM ? uint64_t(BK * ES) : uint64_t(g.lda) * (BK * ES));
+      const uint64_t step_b = uniform(B_KM ? uint64_t(BK * ES) : uint64_t(g.ldb) * (BK * ES));
+      const int lk_a = A_KM && GS == 2 ? 2 * lk : lk, lk_b = B_KM && GS == 2 ? 2 * lk : lk;
+      const uint32_t rda = lds0 + uint32_t(A_KM ? (a_mn * LoadA::S + lk_a) * ES : (lk * LoadA::S + a_mn) * ES);
+      const uint32_t rdb = lds0 + uint32_t(K::A_ELEMS * ES) + uint32_t(B_KM ? (b_mn * LoadB::S + lk_b) * ES : (lk * LoadB::S + b_mn) * ES);
+      const uint32_t wra = lds0 + uint32_t(((tid / LoadA::PER_ROW) * LoadA::S + (tid % LoadA::PER_ROW) * V) * ES);
+      const uint32_t wrb = lds0 + uint32_t(K::A_ELEMS * ES) + uint32_t(((tid / LoadB::PER_ROW) * LoadB::S + (tid % LoadB::PER_ROW) * V) * ES);
+      typename KL::acc_t accv[KL::ACC_CHUNKS];
+      typename KL::sta_t sta;
+      typename KL::stb_t stb;
+      typename KL::fa_t fav[KL::GA];
+      typename KL::fb_t fbv[KL::GA];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < K::MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sta[i][e] = la.reg[i][e], stb[i][e] = lb.reg[i][e];
+        for (int j = 0; j < K::NI; ++j)
 #pragma unroll
-      for (int i = 0; i < K::MI; ++i) fav[2 * i] = fa0[i][0], fav[2 * i + 1] = fa0[i][1];
+          for (int r = 0; r < M::NACC; ++r) {
+            const int L = (i * K::NI + j) * M::NACC + r;
+            accv[L / KL::CHUNK][L % KL::CHUNK] = acc[i][j][r];
+          }
 #pragma unroll
-      for (int j = 0; j < K::NI; ++j) fbv[2 * j] = fb0[j][0], fbv[2 * j + 1] = fb0[j][1];
-      KL::run(acc, sta, stb, fav, fbv, goa[0], goa[1], gob[0], gob[1], rda, rdb, wra, wrb, base_a, base_b, step_a, step_b,
+      for (int i = 0; i < KL::NVA; ++i)
+#pragma unroll
+        for (int e = 0; e < V; ++e) sta[i * V + e] = la.reg[i][e];
+#pragma unroll
+      for (int i = 0; i < KL::NVB; ++i)
+#pragma unroll
+        for (int e = 0; e < V; ++e) stb[i * V + e] = lb.reg[i][e];
+#pragma unroll
+      for (int s = 0; s < KL::GA; ++s) {
+#pragma unroll
+        for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+          for (int e = 0; e < GS; ++e) fav[s][i * GS + e] = fa[s][i][e];
+#pragma unroll
+        for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+          for (int e = 0; e < GS; ++e) fbv[s][j * GS + e] = fb[s][j][e];
+      }
+      KL::run(accv, sta, stb, fav, fbv, goa, gob, rda, rdb, wra, wrb, base_a, base_b, step_a, step_b,
               __builtin_amdgcn_readfirstlane(iters));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < K::MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) la.reg[i][e] = sta[i][e], lb.reg[i][e] = stb[i][e];
+        for (int j = 0; j < K::NI; ++j)
 #pragma unroll
-      for (int i = 0; i < K::MI; ++i) fa0[i][0] = fav[2 * i], fa0[i][1] = fav[2 * i + 1];
+          for (int r = 0; r < M::NACC; ++r) {
+            const int L = (i * K::NI + j) * M::NACC + r;
+            acc[i][j][r] = accv[L / KL::CHUNK][L % KL::CHUNK];
+          }
 #pragma unroll
-      for (int j = 0; j < K::NI; ++j) fb0[j][0] = fbv[2 * j], fb0[j][1] = fbv[2 * j + 1];
+      for (int i = 0; i < KL::NVA; ++i)
+#pragma unroll
+        for (int e = 0; e < V; ++e) la.reg[i][e] = sta[i * V + e];
+#pragma unroll
+      for (int i = 0; i < KL::NVB; ++i)
+#pragma unroll
+        for (int e = 0; e < V; ++e) lb.reg[i][e] = stb[i * V + e];
+#pragma unroll
+      for (int s = 0; s < KL::GA; ++s) {
+#pragma unroll
+        for (int i = 0; i < K::MI; ++i)
+#pragma unroll
+          for (int e = 0; e < GS; ++e) fa[s][i][e] = fav[s][i * GS + e];
+#pragma unroll
+        for (int j = 0; j < K::NI; ++j)
+#pragma unroll
+          for (int e = 0; e < GS; ++e) fb[s][j][e] = fbv[s][j * GS + e];
+      }
       const int64_t adv_a = int64_t(2 * iters) * (A_KM ? int64_t(BK) : int64_t(BK) * g.lda);
       const int64_t adv_b = int64_t(2 * iters) * (B_KM ? int64_t(BK) : int64_t(BK) * g.ldb);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) la.ptr[i] += adv_a, lb.ptr[i] += adv_b;
+      for (int i = 0; i < KL::NVA; ++i) la.ptr[i] += adv_a;
+#pragma unroll
+      for (int i = 0; i < KL::NVB; ++i) lb.ptr[i] += adv_b;
       return 2 * iters;
     }
     return 0;
@@ -731,7 +786,7 @@ struct GemmBody {
     fetch_group(buf0, buf0 + K::A_ELEMS, 0, a_mn, b_mn, lane, fa[0], fb[0]);
 
     int kt = 0;
-    if constexpr (KLOOP_ASM) kt = run_kloop_asm(g, a, b, m0, n0, k_begin, nfull, smem, tid, a_mn, b_mn, fa[0], fb[0]);
+    if constexpr (KLOOP_ASM && KL::GA == 1) kt = run_kloop_asm(g, a, b, m0, n0, k_begin, nfull, smem, tid, a_mn, b_mn, fa, fb);
     for (; kt + 2 < nfull; ++kt) {
       SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
       SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;
