@@ -601,6 +601,7 @@ struct GemmBody {
     fetch_group(buf0, buf0 + K::A_ELEMS, 1, a_mn, b_mn, lane, fa[1], fb[1]);
 
     int kt = 0;
+    if constexpr (KLOOP_ASM && KL::GA == 2) kt = run_kloop_asm(g, a, b, m0, n0, k_begin, nfull, smem, tid, a_mn, b_mn, fa, fb);
     for (; kt + 2 < nfull; ++kt) {
       SBAMD_LDS T* cur = (kt & 1) ? buf1 : buf0;
       SBAMD_LDS T* nxt = (kt & 1) ? buf0 : buf1;

@@ -374,6 +374,11 @@ for ta, tb in ((False, True), (True, False)):
 for ta in (False, True):
     for tb in (False, True):
         CONFIGS.append(Cfg("double", 256, 128, 16, 4, 2, ta, tb, 1))
+        # the smaller fp32 tiles: 128 x 128 x 32 on eight wavefronts of 32 x 64; 64 x 64 on four wavefronts of one
+        # matrix tile each (fragments two groups ahead), K steps of 32 and 64
+        CONFIGS.append(Cfg("float", 128, 128, 32, 4, 2, ta, tb, 1))
+        CONFIGS.append(Cfg("float", 64, 64, 32, 2, 2, ta, tb, 2))
+        CONFIGS.append(Cfg("float", 64, 64, 64, 2, 2, ta, tb, 2))
 
 
 def main():
