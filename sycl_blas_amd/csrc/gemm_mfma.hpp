@@ -632,10 +632,9 @@ struct GemmBody {
   // The steady-state K loop in assembly (gemm_kloop_asm.hpp) for the tile shapes that have a block there.  Called
   // with the state the compiled loop has at kt = 0 (tile 0 in buffer 0, tile 1 on its way into the staging
   // registers, the pointers at tile 2, the first GA fragment groups of tile 0 in fa[0..GA) / fb[0..GA)); runs an
-  // even number of K steps, leaves the same state for kt = that number and returns it (0: not taken).  Taken
-  // for tiles that lie wholly inside the matrices (the block addresses global memory as a scalar base plus a
-  // 32-bit per-lane offset, without the clamping of edge tiles) whose leading dimensions keep those offsets
-  // below 2^32.
+  // even number of K steps, leaves the same state for kt = that number and returns it (0: not taken).  The
+  // block addresses global memory as a scalar base (the tile's origin) plus a 32-bit per-lane offset: taken
+  // whenever the leading dimensions keep those offsets below 2^32.
   using KL = KLoop<T, BM, BN, BK, WM, WN, TA, TB>;
   static constexpr bool KLOOP_ASM = SBAMD_KLOOP_ASM && !SBAMD_ABLATE && std::is_same<MS, Mfma<T>>::value && KL::available &&
                                     KL::MI == K::MI && KL::NI == K::NI;
@@ -652,29 +651,28 @@ struct GemmBody {
       constexpr int64_t ROWS_A = int64_t(LoadA::NVEC) / LoadA::PER_ROW, ROWS_B = int64_t(LoadB::NVEC) / LoadB::PER_ROW;
       const bool offsets_fit = ((ROWS_A - 1) * g.lda + LoadA::PER_ROW * V) * ES < (int64_t(1) << 32) &&
                                ((ROWS_B - 1) * g.ldb + LoadB::PER_ROW * V) * ES < (int64_t(1) << 32);
-      if (iters < 1 || m0 + BM > g.m || n0 + BN > g.n || !offsets_fit) return 0;
+      if (iters < 1 || !offsets_fit) return 0;
       const int lk = M::lane_k(tid & 63);
       const uint32_t lds0 = uint32_t(uintptr_t(smem));
+      const int64_t k2 = k_begin + 2 * BK;  // the pointers stand at tile 2
+      // Per-lane offsets from the tile's origin to where the lane's pointers stand: for a tile that hangs over the
+      // edge those pointers were clamped to the last valid row / vector by init_fast, and the offsets carry the
+      // clamping (they stay non-negative: the tile's origin is its smallest address).
+      const T* origin_a = A_KM ? a + k2 + m0 * g.lda : a + m0 + k2 * g.lda;
+      const T* origin_b = B_KM ? b + k2 + n0 * g.ldb : b + n0 + k2 * g.ldb;
       uint32_t goa[KL::NVA], gob[KL::NVB];
 #pragma unroll
-      for (int i = 0; i < KL::NVA; ++i) {
-        const int v = tid + i * K::NT;
-        goa[i] = uint32_t(((v % LoadA::PER_ROW) * V + int64_t(v / LoadA::PER_ROW) * g.lda) * ES);
-      }
+      for (int i = 0; i < KL::NVA; ++i) goa[i] = uint32_t((la.ptr[i] - origin_a) * ES);
 #pragma unroll
-      for (int i = 0; i < KL::NVB; ++i) {
-        const int v = tid + i * K::NT;
-        gob[i] = uint32_t(((v % LoadB::PER_ROW) * V + int64_t(v / LoadB::PER_ROW) * g.ldb) * ES);
-      }
-      const int64_t k2 = k_begin + 2 * BK;  // the pointers stand at tile 2
+      for (int i = 0; i < KL::NVB; ++i) gob[i] = uint32_t((lb.ptr[i] - origin_b) * ES);
       // wave-uniform by construction; say so to the compiler (the block takes them in scalar registers)
       auto uniform = [](uint64_t v) {
         const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
         const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))));
         return (uint64_t(hi) << 32) | uint64_t(lo);
       };
-      uint64_t base_a = uniform(uint64_t(uintptr_t(A_KM ? a + k2 + m0 * g.lda : a + m0 + k2 * g.lda)));
-      uint64_t base_b = uniform(uint64_t(uintptr_t(B_KM ? b + k2 + n0 * g.ldb : b + n0 + k2 * g.ldb)));
+      uint64_t base_a = uniform(uint64_t(uintptr_t(origin_a)));
+      uint64_t base_b = uniform(uint64_t(uintptr_t(origin_b)));
       const uint64_t step_a = uniform(A_KM ? uint64_t(BK * ES) : uint64_t(g.lda) * (BK * ES));
       const uint64_t step_b = uniform(B_KM ? uint64_t(BK * ES) : uint64_t(g.ldb) * (BK * ES));
       const int lk_a = A_KM && GS == 2 ? 2 * lk : lk, lk_b = B_KM && GS == 2 ? 2 * lk : lk;

@@ -379,6 +379,9 @@ for ta in (False, True):
         CONFIGS.append(Cfg("float", 128, 128, 32, 4, 2, ta, tb, 1))
         CONFIGS.append(Cfg("float", 64, 64, 32, 2, 2, ta, tb, 2))
         CONFIGS.append(Cfg("float", 64, 64, 64, 2, 2, ta, tb, 2))
+        # the smaller fp64 tiles: 128 x 128 x 16 and 64 x 64 x 16 on four wavefronts (16 / 4 matrix tiles each)
+        CONFIGS.append(Cfg("double", 128, 128, 16, 2, 2, ta, tb, 1))
+        CONFIGS.append(Cfg("double", 64, 64, 16, 2, 2, ta, tb, 1))
 
 
 def main():
