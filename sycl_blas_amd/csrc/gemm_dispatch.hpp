@@ -97,17 +97,19 @@ hipError_t launch_dma_tile(GemmArgs<float> g, hipStream_t stream) {
   return launch_dma_one<BM, BN, BK, WM, WN, OCC, STAGES, false, true>(g, nz, stream);  // A 'n', B 't' (dma_ok)
 }
 
-// Should the direct-to-LDS kernel take this launch?  (K range per slice in whole K steps of `bk`.)
-// Only with both operands M/N-contiguous (A 'n', B 't'): their linear [k][mn] image is read without bank
-// conflicts.  A K-contiguous operand can only be swizzled in 16-byte pieces, which leaves its fragment
-// reads two-way conflicted, and measured slower than the register-staged kernel with its padded rows
-// (1024^3 on 64x64 tiles: NT 29.7 -> 27.1 us, but NN 31.0 -> 32.0, TN 31.7 -> 34.2).  On the 128x128 and
-// 256x256 tiles the register-staged pipeline with its pinned instruction interleave stays ahead by 1-3 %
-// (2048^3 NT: 139.8 us against 142.6), so only the 64x64 tile uses it.
+// Should the direct-to-LDS kernel (gemm_mfma_dma_kernel) take this launch?  Not any more by itself: it was ahead of
+// the compiled register-staged loop on the 64 x 64 tile with both operands M/N-contiguous (1024^3 NT 29.7 -> 27.1 us),
+// but the register-staged tiles now run their K loop as a hand-scheduled assembly block (gemm_kloop_asm.hpp) and
+// are ahead of it everywhere measured (NT 1024^3: 20.8 us against 20.6, 2048^3: 124.7 us against 141.3).  The kernel
+// stays reachable for A/B timing: SBAMD_DMA_TILES=1 in the environment restores the old rule (same bits either way).
 template <typename T>
 inline bool dma_ok(const GemmArgs<T>& g, bool ta, bool tb, int64_t k_span, int bk) {
   if constexpr (sizeof(T) != 4) return false;
-  return !ta && tb && g.vec_a && g.vec_b && k_span >= 2 * bk && g.m % 4 == 0 && g.n % 4 == 0;
+  static const bool enabled = [] {
+    const char* e = std::getenv("SBAMD_DMA_TILES");
+    return e && e[0] == '1';
+  }();
+  return enabled && !ta && tb && g.vec_a && g.vec_b && k_span >= 2 * bk && g.m % 4 == 0 && g.n % 4 == 0;
 }
 
 // Batches of one-tile, one-step items on a fixed set of workgroups (gemm_batch_stream_kernel).
@@ -316,41 +318,42 @@ struct CostOverheads {
 };
 template <>
 struct CostModel<float> {
-  // Fitted to a sweep in which every candidate was timed after 15 ms of its own launches (timed cold, right after
-  // whatever ran before, candidates read up to 9 % apart from themselves and the fit carried that noise:
-  // small_k {0.0181, 0.0372, 0.0555, 0.0726}, large_k {0.0700, 0.1223}, huge_k 0.2416 before).  The fit said
-  // small_k {0.0175, 0.0338, 0.0506, 0.0657}, large_k {0.0605, 0.1155}, huge_k 0.2395; entries it gets mostly
-  // from short K slabs are set from long single launches instead: 64 x 64 alone on a unit 0.0181 (1024^3) and
-  // 0.0179 (1024 x 1024 x 16384), with company 0.0364 (1024 x 2048 x 4096); 128 x 128 0.0621 (2048 x 2048 x 1024)
-  // and, two per unit, 0.1166 over 8192^3's eight rounds (0.1233 over 4096^3's two, which start and end together);
-  // 256 x 256 0.2286 at 8192^3 and 0.2339 at 4096^3 -- it has to stay ahead of 128 x 128 on both, as measured.
-  static constexpr double small_k[4] = {0.0180, 0.0355, 0.0530, 0.0690};
-  static constexpr double large_k[2] = {0.0620, 0.1165};
-  static constexpr double huge_k[1] = {0.2300};  // 256 x 256 tile
-  // 96 x 96 tile on the 16x16x4 instruction, one / two workgroups per unit (medians over the sweep's shapes with
-  // at least 200 such tiles; 1536^3, 256 tiles: 64.5 us; 3072^3, 1024 tiles: 454 us)
+  // Fitted (tools/fit_cost_model.py) to a sweep of every candidate, each timed after 15 ms of its own launches,
+  // taken with the tiles' K loops running as assembly blocks (profiles/r03/suites/tune_sweep_f32.csv; the compiled
+  // loops' constants were small_k {0.0180, 0.0355, 0.0530, 0.0690}, large_k {0.0620, 0.1165}, huge_k 0.2300).  The
+  // fit said small_k {0.0134, 0.0287, 0.0421, 0.0579}, large_k {0.0556, 0.1107}, huge_k 0.2272; entries it gets
+  // mostly from short K slabs are set from long single launches instead: 64 x 64 alone on a unit 0.0145
+  // (1024 x 1024 x 4096), four per unit 0.0595-0.0603 (4096^3, 8192^3); 128 x 128 alone 0.0562 (2048 x 2048 x 16384),
+  // two per unit 0.1146 (4096^3) and 0.1183 (8192^3); 256 x 256 0.2197 (8192^3) and 0.2229 (4096^3) -- it has to
+  // stay ahead of 128 x 128 on both, as measured.
+  static constexpr double small_k[4] = {0.0140, 0.0290, 0.0435, 0.0597};
+  static constexpr double large_k[2] = {0.0565, 0.1160};
+  static constexpr double huge_k[1] = {0.2200};  // 256 x 256 tile
+  // 96 x 96 tile on the 16x16x4 instruction, one / two workgroups per unit (compiled loop; 3072^3, 1024 tiles:
+  // 462 us -> 0.0744; 1536^3, 256 tiles: 64.5 us)
   static constexpr double medium_k[2] = {0.0400, 0.0748};
-  // 192 x 192 tile on the same instruction, eight wavefronts of 96 x 48, one workgroup per unit (3072^3, 256 tiles: 415 us)
+  // 192 x 192 tile on the same instruction, eight wavefronts of 96 x 48, one workgroup per unit (3072^3, 256 tiles:
+  // 418 us; 6144^3, 1024 tiles: 3300 us -> 0.1345)
   static constexpr double wide_k[1] = {0.1350};
-  // two K halves in one workgroup, relative to two resident workgroups of the tile {64x64, 128x128}
-  // (medians over the sweep's shapes that leave at least half of a unit's workgroup slots empty)
-  static constexpr double halves_factor[2] = {1.020, 1.046};
-  static constexpr CostOverheads over = {3.66, 6.98, 5.87e6, 0.0498};
+  // two K halves in one workgroup, relative to two resident workgroups of the tile {64x64, 128x128}: 64 x 64 the
+  // fit's median over the sweep; 128 x 128 from long launches (8192^3 0.960, 6144^3 0.966, 4096^3 0.976,
+  // 2048 x 2048 x 16384 0.952)
+  static constexpr double halves_factor[2] = {0.981, 0.965};
+  static constexpr CostOverheads over = {4.71, 7.43, 5.63e6, 0.0497};
 };
 template <>
 struct CostModel<double> {
-  // refitted after the 64 x 64 kernel lost its accumulator copies (one workgroup per unit: 0.0460 -> 0.0380 us).
-  // A refit to the sweep with every candidate timed after 15 ms of its own launches (small_k {0.0366, 0.0724,
-  // 0.0915, 0.1205}, large_k {0.1193, 0.2317}, halves {0.872, 0.997}) chose worse on that same sweep (auto / best
-  // 90th percentile 1.10 against 1.07 with these), for the reason given at float's constants; these stay.
-  static constexpr double small_k[4] = {0.0380, 0.0785, 0.1027, 0.1300};
-  static constexpr double large_k[2] = {0.1205, 0.2393};
-  static constexpr double huge_k[1] = {0.2346};
-  // 96 x 96 (1536^3: 112 us against 149 on 64 x 64; 3072^3: 822 us) and 192 x 192 (3072^3: 805 us), tools/step_lab.hip d
-  static constexpr double medium_k[2] = {0.0705, 0.1380};
-  static constexpr double wide_k[1] = {0.2640};
-  static constexpr double halves_factor[2] = {0.807, 0.967};
-  static constexpr CostOverheads over = {5.12, 7.20, 5.83e6, 0.0397};
+  // Same procedure (profiles/r03/suites/tune_sweep_f64.csv).  The fit: small_k {0.0335, 0.0693, 0.0815, 0.1149},
+  // large_k {0.1128, 0.2205}, huge_k 0.2247, halves {0.789, 0.998}; from long single launches 256 x 128 runs
+  // 0.2184 (8192^3) and 0.2225 (4096^3), 128 x 128 two per unit 0.2196 / 0.2235, alone 0.1113.
+  static constexpr double small_k[4] = {0.0335, 0.0693, 0.0815, 0.1149};
+  static constexpr double large_k[2] = {0.1120, 0.2215};
+  static constexpr double huge_k[1] = {0.2200};
+  // 96 x 96 (3072^3: 838 us -> 0.1354 for two per unit) and 192 x 192 (3072^3: 807 us; 6144^3: 6350 us -> 0.2584)
+  static constexpr double medium_k[2] = {0.0705, 0.1360};
+  static constexpr double wide_k[1] = {0.2600};
+  static constexpr double halves_factor[2] = {0.800, 0.998};
+  static constexpr CostOverheads over = {6.16, 6.81, 6.25e6, 0.0438};
 };
 
 template <typename T>
@@ -458,11 +461,16 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
   for (int tile = TILE_64; tile <= TILE_128; ++tile) {
     const int edge = tile == TILE_128 ? 128 : 64, occ = tile == TILE_128 ? 2 : 4;
     if (k % (2 * Mfma<T>::V) != 0 || k < 512) continue;  // equal, vector-aligned halves; short K: the hand-over is not free
-    if (ceil_div(m, edge) * ceil_div(n, edge) * 2 > int64_t(cus) * occ) continue;
+    // 64 x 64: only where the tiles alone leave at least half of a unit's workgroup slots empty (the measured
+    // factor is the gain of doubling the wavefronts of an under-filled unit; on a full unit there is none).
+    // 128 x 128: any tile count -- a workgroup of two sets has a unit to itself, which also evens out tile counts
+    // that leave the last round of two-per-unit workgroups half empty (fp32 6144^3: 2304 tiles are nine per unit,
+    // 148 TFLOP/s this way against 132).
+    if (tile == TILE_64 && ceil_div(m, edge) * ceil_div(n, edge) * 2 > int64_t(cus) * occ) continue;
     const double us = estimate_us<T>(tile, 2, m, n, k, 1, cus, true);
-    // 5 % suffices here (a cut through the cube has to win 10 %): the cut is always in two equal halves,
+    // 4 % suffices here, 2 % for the 128 x 128 tile, whose model is built from long launches (a cut through the cube has to win 10 %): the cut is always in two equal halves,
     // whatever the device, and costs neither a second launch nor a trip through memory
-    if (us < 0.95 * best_us && us < chosen_us) chosen_us = us, chosen = {tile, 2, true};
+    if (us < (tile == TILE_128 ? 0.98 : 0.96) * best_us && us < chosen_us) chosen_us = us, chosen = {tile, 2, true};
   }
   return chosen;
 }

@@ -58,7 +58,8 @@ def walk_general(h, rng, cases, log=None):
 
 
 def walk_mid(h, rng, cases, log=None):
-    """Mid-size products under the planner's own choice, which is often the 96- or 192-row tile there."""
+    """Mid-size products under the planner's own choice.  Every second case has at most one 96 x 96 tile per
+    compute unit of a 256-unit part (15 or 16 tiles along each edge), where the planner takes that tile."""
     seen = {}
     h.set_kernel(_lib.KERNEL_AUTO)
     for i in range(cases):
@@ -67,6 +68,8 @@ def walk_mid(h, rng, cases, log=None):
         if rng.integers(0, 2):
             m, n = (m + 95) // 96 * 96, (n + 95) // 96 * 96
         k = int(rng.integers(40, 260))
+        if i % 2:
+            m, n, k = int(rng.choice([1440, 1536])), int(rng.choice([1440, 1536])), int(rng.integers(64, 600))
         ta, tb = str(rng.choice(["n", "t"])), str(rng.choice(["n", "t"]))
         verify_gemm(h, dtype, 0, 1, m, n, k, ta, tb, 1.5, float(rng.choice([0.0, 0.5])), 1, 1, 1)
         ran = h.last_kernel()

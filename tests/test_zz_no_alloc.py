@@ -124,7 +124,7 @@ def test_noalloc_allocates_nothing_on_a_fresh_handle(sb_handle):
         cut = fresh.last_splitk()
         fresh.wait()
         after = _free_bytes(hip)
-        assert cut[0] > 1 and cut[0] * m * n * 4 >= (8 << 20), "the shape must need a cube worth noticing"
+        assert cut[0] > 1 and cut[0] * m * n * 4 >= (2 << 20), "the shape must need a cube that an allocation would show"
         assert after == before, f"free device memory changed by {before - after} bytes across a no-allocation call"
         call(lib.sbamd_sgemm, h0, c_g[0])
         assert h0.last_splitk() == cut

@@ -110,7 +110,7 @@ def main(path):
         for dt, t, m, n, k, us in fused_rows:
             bm, bn, occ = TILES[t]
             tiles = math.ceil(m / bm) * math.ceil(n / bn)
-            if t != tile or tiles * 2 > CUS * occ or k < 512:
+            if t != tile or k < 512:
                 continue
             busiest = math.ceil(tiles / CUS) * 2
             full, rem = divmod(busiest, occ)
