@@ -283,7 +283,7 @@ def cpu_baseline(dtype, ta, tb, size, seed):
 
 def load_traffic(dtype, trans, size):
     """HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/*.json), or None."""
-    for path in (os.path.join(ROOT, "profiles", "r02", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")):
+    for path in (os.path.join(ROOT, "profiles", "r03", "r03_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r02", "r02_pmc_traffic.json")):
         try:
             with open(path) as f:
                 table = json.load(f)

@@ -35,8 +35,15 @@ for dt, name in names.items():
                               "bench_event_ms": round(line["ms_per_step"], 4)}
 shutil.copy(os.path.join(src, "trace_extras", "trace_kernel_stats.csv"), os.path.join(dst, f"{tag}_all_kernels_stats.csv"))
 json.dump(timed, open(os.path.join(dst, f"{tag}_kernel_trace_timed_steps.json"), "w"), indent=1)
+traffic = {"_note": "HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes of `bench.py --steps 3 "
+                    f"--warmup 1` (tools/pmc_pass.sh, summaries in {tag}_{{s,d}}gemm8192_nn_pmc.txt); FETCH_SIZE is reported in KiB and "
+                    "counts 128-byte requests as 64 bytes on gfx950, so it is multiplied by 1024 and by 2; WRITE_SIZE by 1024. "
+                    "Infinity-Cache hits are included in FETCH_SIZE."}
 for dt, name in names.items():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"),
                           os.path.join(root, "gpurun_out", f"pmc_{tag}_{dt}nn")], capture_output=True, text=True, check=True).stdout
     open(os.path.join(dst, f"{tag}_{name}_nn_pmc.txt"), "w").write(out)
+    found = {w[0]: float(w[1]) for w in (l.split() for l in out.splitlines()) if len(w) > 1 and w[0] in ("FETCH_SIZE", "WRITE_SIZE")}
+    traffic[f"{dt}_nn_8192"] = int(found["FETCH_SIZE"] + found["WRITE_SIZE"])
+json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(timed, indent=1))
