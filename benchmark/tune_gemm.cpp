@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,7 +28,7 @@
 
 namespace {
 
-FILE* g_csv = nullptr;  // --csv=FILE: one line per candidate (dtype,ta,tb,m,k,n,bs,kernel,tile,depth,ms,fused)
+FILE* g_csv = nullptr;  // --csv=FILE: one line per candidate (dtype,ta,tb,m,k,n,bs,kernel,tile,depth,ms,fused, then as launched: kernel,tile_m,tile_n,depth,fused)
 
 void check(int st, sbamd_handle_t h, const char* what) {
   if (st == SBAMD_OK) return;
@@ -48,6 +49,8 @@ struct Outcome {
   double ms = 0, gflops = 0;
   bool ok = false, same_bits = true;
   std::string note;
+  int ran_kernel = -1, ran_tile_m = 0, ran_tile_n = 0, ran_fused = 0;  // what the library reports it launched
+  int64_t ran_depth = 1, ran_chunk = 0;
 };
 
 template <typename T>
@@ -88,20 +91,20 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     cands.push_back({"small   64x64  tile, register-staged only", SBAMD_KERNEL_SMALL, 1, true});
     if (m * n * bs <= 1024 * 1024) cands.push_back({"tiny    32x32  tile, 1 wave", SBAMD_KERNEL_TINY, 0, true});
     if (bs == 1) {
-      static const char* tile_names[] = {"", "64x64", "128x128", sizeof(T) == 4 ? "256x256" : "256x128"};
-      for (int tile = 1; tile <= 3; ++tile)
-        for (int depth : {2, 4, 8, 16, 32, 64, 128, 256}) {
+      static const char* tile_names[] = {"", "64x64", "128x128", sizeof(T) == 4 ? "256x256" : "256x128", "", "", "96x96", "192x192"};
+      for (int tile : {1, 2, 3, 6, 7})
+        for (int depth : {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256}) {
           if (k / depth < 64) break;
           // more slabs than it takes to give every compute unit four workgroups only add traffic
-          const int64_t bm = tile == 3 ? 256 : tile == 2 ? 128 : 64;
-          const int64_t bn = tile == 1 ? 64 : (tile == 3 && sizeof(T) == 4) ? 256 : 128;
+          const int64_t bm = tile == 3 ? 256 : tile == 2 ? 128 : tile == 6 ? 96 : tile == 7 ? 192 : 64;
+          const int64_t bn = tile == 3 ? (sizeof(T) == 4 ? 256 : 128) : bm;
           const int64_t tiles = ((m + bm - 1) / bm) * ((n + bn - 1) / bn);
           if (tiles * depth > 4096 && depth > 2) break;
           cands.push_back({std::string("splitk ") + tile_names[tile] + " depth " + std::to_string(depth),
                            SBAMD_KERNEL_SPLITK, depth | (tile << 16), false});
         }
       // both halves of K in one workgroup (falls back to the cube route when K does not split into whole K steps)
-      for (int tile = 1; tile <= 2; ++tile)
+      for (int tile : {1, 2, 6})
         cands.push_back({std::string("halves ") + tile_names[tile] + " (two K halves per workgroup)", SBAMD_KERNEL_SPLITK,
                          2 | (tile << 16) | (1 << 24), false});
     }
@@ -135,6 +138,9 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
       check(call(), h, "gemm");  // warm-up and the run whose result is compared
       check(sbamd_copy_to_host(h, got.data(), c, got.size() * sizeof(T)), h, "copy");
       check(sbamd_wait(h), h, "wait");
+      o.ran_kernel = sbamd_last_kernel(h);
+      sbamd_last_splitk(h, &o.ran_depth, &o.ran_chunk);
+      sbamd_last_tile(h, &o.ran_tile_m, &o.ran_tile_n, &o.ran_fused);
       if (cand.kernel == SBAMD_KERNEL_AUTO) {
         int64_t depth = 1, chunk = 0;
         sbamd_last_splitk(h, &depth, &chunk);
@@ -158,16 +164,24 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
           check(sbamd_wait(h), h, "wait");
         } while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(15));
       }
-      sbamd_event_t e0 = nullptr, e1 = nullptr;
-      check(sbamd_event_record(h, &e0), h, "event");
-      for (int i = 0; i < rep; ++i) check(call(), h, "gemm");
-      check(sbamd_event_record(h, &e1), h, "event");
-      check(sbamd_wait(h), h, "wait");
-      float ms = 0;
-      check(sbamd_event_elapsed_ms(e0, e1, &ms), h, "elapsed");
-      sbamd_event_destroy(e0);
-      sbamd_event_destroy(e1);
-      o.ms = double(ms) / rep;
+      // A timed loop of `rep` calls, then three loops long enough to last a millisecond each (a loop of ten
+      // 10-microsecond launches reads 10 % off from run to run); the shortest loop counts.
+      auto timed = [&](int calls) {
+        sbamd_event_t e0 = nullptr, e1 = nullptr;
+        check(sbamd_event_record(h, &e0), h, "event");
+        for (int i = 0; i < calls; ++i) check(call(), h, "gemm");
+        check(sbamd_event_record(h, &e1), h, "event");
+        check(sbamd_wait(h), h, "wait");
+        float ms = 0;
+        check(sbamd_event_elapsed_ms(e0, e1, &ms), h, "elapsed");
+        sbamd_event_destroy(e0);
+        sbamd_event_destroy(e1);
+        return double(ms) / calls;
+      };
+      o.ms = timed(rep);
+      const int longer = int(std::min(400.0, std::ceil(1.0 / std::max(o.ms, 1e-4))));
+      if (longer > rep)
+        for (int round = 0; round < 3; ++round) o.ms = round == 0 ? timed(longer) : std::min(o.ms, timed(longer));
       o.gflops = flops / (o.ms * 1e6);
       o.ok = true;
     } catch (const std::exception& e) {
@@ -193,9 +207,11 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
     std::printf("  %-32s %10.4f ms %12.1f GFLOP/s  %s%s\n", o.cand.name.c_str(), o.ms, o.gflops, o.note.c_str(),
                 o.same_bits ? "" : "  RESULT DIFFERS");
     if (g_csv)
-      std::fprintf(g_csv, "%s,%c,%c,%lld,%lld,%lld,%lld,%d,%d,%d,%.6f,%d\n", sizeof(T) == 4 ? "float" : "double", ta, tb,
+      // the candidate as pinned (kernel, tile, depth, fused), then what the library reports it ran
+      std::fprintf(g_csv, "%s,%c,%c,%lld,%lld,%lld,%lld,%d,%d,%d,%.6f,%d,%d,%d,%d,%lld,%d\n", sizeof(T) == 4 ? "float" : "double", ta, tb,
                    (long long)m, (long long)k, (long long)n, (long long)bs, o.cand.kernel, (o.cand.param >> 16) & 0xff,
-                   o.cand.param & 0xffff, o.ms, (o.cand.param >> 24) & 1);
+                   o.cand.param & 0xffff, o.ms, (o.cand.param >> 24) & 1, o.ran_kernel, o.ran_tile_m, o.ran_tile_n,
+                   (long long)o.ran_depth, o.ran_fused);
   }
   for (const Outcome& o : outcomes)
     if (o.ok && !o.same_bits) throw std::runtime_error("kernel families disagree on this shape");

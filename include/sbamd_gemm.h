@@ -131,6 +131,13 @@ int sbamd_last_kernel(sbamd_handle_t h);
  * checker needs it to reproduce the result exactly. */
 int sbamd_last_splitk(sbamd_handle_t h, int64_t* depth, int64_t* k_chunk);
 
+/* The macro tile (rows x columns of C per workgroup) the last sbamd_sgemm / sbamd_dgemm family call ran its
+ * matrix-instruction kernel on, and whether a cut in two was done inside one workgroup (`fused`, no cube).
+ * 0 x 0 when the call launched no such kernel (the one-element-per-lane and interleaved kernels, alpha == 0) and
+ * after the 16-bit entry points.  A tuning hook like sbamd_last_kernel (the reference reports its configuration
+ * as a string, gemm_local.hpp:161-178 get_type_string); it does not affect results. */
+int sbamd_last_tile(sbamd_handle_t h, int* tile_m, int* tile_n, int* fused);
+
 /* How the last _trsm call on this handle was carried out: `diag` = launches of the
  * kernel that solves a whole diagonal super-block (up to 128 rows) at once, `panel` =
  * launches that apply the updates of many 16-wide blocks to a panel in one pass.  Both

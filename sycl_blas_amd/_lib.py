@@ -57,6 +57,7 @@ SIGNATURES = {
     "sbamd_set_kernel": (_int, [_vp, _int, _int]),
     "sbamd_last_kernel": (_int, [_vp]),
     "sbamd_last_splitk": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sbamd_last_tile": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "sbamd_last_trsm_launches": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sbamd_event_record": (_int, [_vp, C.POINTER(_vp)]),
     "sbamd_stream_wait_event": (_int, [_vp, _vp]),

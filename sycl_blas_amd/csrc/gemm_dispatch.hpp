@@ -162,10 +162,10 @@ hipError_t launch_stream(const GemmArgs<T>& g, bool ta, bool tb, int cus, hipStr
 }
 
 // Both halves of K in one workgroup (gemm_mfma_halves_kernel); g.k_chunk = k / 2.
-template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB, typename MS = Mfma<T>>
 hipError_t launch_halves_one(const GemmArgs<T>& g, hipStream_t stream) {
-  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
-  auto kernel = gemm_mfma_halves_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC>;
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB, MS>;
+  auto kernel = gemm_mfma_halves_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC, MS>;
   constexpr size_t lds = 2 * K::LDS_BYTES;
   static_assert(lds <= 160 * 1024, "two sets of buffers must fit the LDS");
   static PerDeviceOnce lds_limit;
@@ -180,16 +180,16 @@ hipError_t launch_halves_one(const GemmArgs<T>& g, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, typename MS = Mfma<T>>
 hipError_t launch_halves(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
   g.tiles_m = int32_t(ceil_div(g.m, BM));
   g.tiles_n = int32_t(ceil_div(g.n, BN));
   if (ta) {
-    return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, true>(g, stream)
-              : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, false>(g, stream);
+    return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, true, MS>(g, stream)
+              : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, false, MS>(g, stream);
   }
-  return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, true>(g, stream)
-            : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, false>(g, stream);
+  return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, true, MS>(g, stream)
+            : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, false, MS>(g, stream);
 }
 
 // The biggest tile: 256 x 256 (float) / 256 x 128 (double), eight waves as 4 (M) x 2 (N).
@@ -293,7 +293,9 @@ struct Tiles<double> {
 };
 
 // What to launch: a tile shape and how many K slabs (1 = a single kernel).
-enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5, TILE_96 = 6, TILE_192 = 7 };  // TILE_96 / TILE_192: single launches only
+enum { TILE_64 = 1, TILE_128 = 2, TILE_256 = 3, TILE_32 = 4, TILE_NAIVE = 5, TILE_96 = 6, TILE_192 = 7 };
+// the tiles a K cut may run on (the cube route; two halves in one workgroup: 64, 128 and 96)
+inline bool tile_cuts_k(int tile) { return (tile >= TILE_64 && tile <= TILE_256) || tile == TILE_96 || tile == TILE_192; }
 struct Plan {
   int tile;
   int64_t depth;
@@ -338,7 +340,7 @@ struct CostModel<float> {
   // two K halves in one workgroup, relative to two resident workgroups of the tile {64x64, 128x128}: 64 x 64 the
   // fit's median over the sweep; 128 x 128 from long launches (8192^3 0.960, 6144^3 0.966, 4096^3 0.976,
   // 2048 x 2048 x 16384 0.952)
-  static constexpr double halves_factor[2] = {0.981, 0.965};
+  static constexpr double halves_factor[3] = {0.981, 0.965, 0.98};  // third: the 96 x 96 tile
   static constexpr CostOverheads over = {4.71, 7.43, 5.63e6, 0.0497};
 };
 template <>
@@ -352,7 +354,7 @@ struct CostModel<double> {
   // 96 x 96 (3072^3: 838 us -> 0.1354 for two per unit) and 192 x 192 (3072^3: 807 us; 6144^3: 6350 us -> 0.2584)
   static constexpr double medium_k[2] = {0.0705, 0.1360};
   static constexpr double wide_k[1] = {0.2600};
-  static constexpr double halves_factor[2] = {0.800, 0.998};
+  static constexpr double halves_factor[3] = {0.800, 0.998, 0.90};
   static constexpr CostOverheads over = {6.16, 6.81, 6.25e6, 0.0438};
 };
 
@@ -397,7 +399,7 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
   const int64_t full = busiest / occ, rem = busiest % occ;
   double us_per_k = double(full) * per_k[occ - 1] + (rem ? per_k[rem - 1] : 0.0);
   const int64_t k_chunk = bk * ceil_div(k, int64_t(bk) * depth);
-  if (fused) us_per_k *= C::halves_factor[tile == TILE_128 ? 1 : 0];
+  if (fused) us_per_k *= C::halves_factor[tile == TILE_128 ? 1 : tile == TILE_96 ? 2 : 0];
   double us = us_per_k * double(k_chunk);
   if (depth > 1 && !fused) {
     us += C::over.t_split + 2.0 * double(m) * double(n) * double(depth) * sizeof(T) / C::over.bw +
@@ -444,11 +446,11 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
   static const int depths[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
   Plan split = best;
   double split_us = 1e300;
-  for (int tile = TILE_64; tile <= TILE_256; ++tile)
+  for (int tile : {TILE_64, TILE_128, TILE_256, TILE_96, TILE_192})
     for (int depth : depths) {
       if (k / depth < 64) break;                                                   // slabs of at least 64
       if (double(m) * double(n) * depth * sizeof(T) > cube_limit) break;           // cube of at most 1 GiB (or what the caller provides)
-      const double us = estimate_us<T>(tile, depth, m, n, k, 1, cus);
+      const double us = (tile > TILE_256 ? 1.03 : 1.0) * estimate_us<T>(tile, depth, m, n, k, 1, cus);
       if (us < split_us) split_us = us, split = {tile, depth};
     }
   Plan chosen = split_us < 0.9 * best_us ? split : best;
@@ -458,18 +460,19 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
   // half of a compute unit's workgroup slots empty (1024^3 fp64 56.7 -> 41.2 us; fp32
   // 28.9 -> 26.6 and 2048^3 fp32 156 -> 138, which the 10 % rule for K cuts turns down);
   // with more tiles it loses to the plain launch.
-  for (int tile = TILE_64; tile <= TILE_128; ++tile) {
-    const int edge = tile == TILE_128 ? 128 : 64, occ = tile == TILE_128 ? 2 : 4;
+  for (int tile : {TILE_64, TILE_128, TILE_96}) {
+    const int edge = tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : 64, occ = tile == TILE_64 ? 4 : 2;
     if (k % (2 * Mfma<T>::V) != 0 || k < 512) continue;  // equal, vector-aligned halves; short K: the hand-over is not free
     // 64 x 64: only where the tiles alone leave at least half of a unit's workgroup slots empty (the measured
     // factor is the gain of doubling the wavefronts of an under-filled unit; on a full unit there is none).
     // 128 x 128: any tile count -- a workgroup of two sets has a unit to itself, which also evens out tile counts
     // that leave the last round of two-per-unit workgroups half empty (fp32 6144^3: 2304 tiles are nine per unit,
     // 148 TFLOP/s this way against 132).
-    if (tile == TILE_64 && ceil_div(m, edge) * ceil_div(n, edge) * 2 > int64_t(cus) * occ) continue;
-    const double us = estimate_us<T>(tile, 2, m, n, k, 1, cus, true);
-    // 4 % suffices here, 2 % for the 128 x 128 tile, whose model is built from long launches (a cut through the cube has to win 10 %): the cut is always in two equal halves,
-    // whatever the device, and costs neither a second launch nor a trip through memory
+    if (tile != TILE_128 && ceil_div(m, edge) * ceil_div(n, edge) * 2 > int64_t(cus) * occ) continue;
+    const double us = (tile == TILE_96 ? 1.03 : 1.0) * estimate_us<T>(tile, 2, m, n, k, 1, cus, true);
+    // 4 % suffices here, 2 % for the 128 x 128 tile, whose model is built from long launches (a cut through the
+    // cube has to win 10 %): the cut is always in two equal halves, whatever the device, and costs neither a
+    // second launch nor a trip through memory
     if (us < (tile == TILE_128 ? 0.98 : 0.96) * best_us && us < chosen_us) chosen_us = us, chosen = {tile, 2, true};
   }
   return chosen;
@@ -562,6 +565,7 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       p.n / 64 < (int64_t(1) << 30)) {
     g.tiles_m = int32_t(p.m / 64);
     g.tiles_n = int32_t(p.n / 64);
+    h->last_tile_m = h->last_tile_n = 64;
     h->last_kernel = SBAMD_KERNEL_STREAM;
     h->last_depth = 1;
     h->last_k_chunk = p.k;
@@ -583,15 +587,15 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       plan = {(h->kernel_param & 1) ? TILE_192 : TILE_96, 1};
       break;
     case SBAMD_KERNEL_SPLITK:
-      if (pin_tile >= TILE_64 && pin_tile <= TILE_256) plan.tile = pin_tile;
-      else if (plan.tile > TILE_256) plan.tile = TILE_64;
+      if (tile_cuts_k(pin_tile)) plan.tile = pin_tile;
+      else if (!tile_cuts_k(plan.tile)) plan.tile = TILE_64;
       if (pin_depth > 0) plan.depth = pin_depth;
       plan.fused = pin_fused;
       if (pin_fused) plan.depth = 2;
       break;
     default: return hipErrorInvalidValue;
   }
-  if (p.batch != 1 || plan.tile > TILE_256) plan.depth = 1;
+  if (p.batch != 1 || !tile_cuts_k(plan.tile)) plan.depth = 1;
   if (plan.tile == TILE_NAIVE) {
     h->last_kernel = SBAMD_KERNEL_NAIVE;
     // pinned: one element per lane.  Chosen for a batch of very small items: its 4 x 4 register-block form once
@@ -602,33 +606,38 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
   }
   if (plan.tile == TILE_32) {
     h->last_kernel = SBAMD_KERNEL_TINY;
+    h->last_tile_m = h->last_tile_n = 32;
     return launch_tile<T, 32, 32, Tiles<T>::TINY_BK, 1, 1, 4>(g, p.ta, p.tb, h->stream);
   }
-  if (plan.tile == TILE_96 || plan.tile == TILE_192) {
-    using MS = typename Tiles<T>::MediumShape;
-    h->last_kernel = SBAMD_KERNEL_MEDIUM;
+  using MS = typename Tiles<T>::MediumShape;
+  const bool medium = plan.tile == TILE_96 || plan.tile == TILE_192;
+  h->last_tile_m = plan.tile == TILE_256 ? 256 : plan.tile == TILE_128 ? 128 : plan.tile == TILE_96 ? 96 : plan.tile == TILE_192 ? 192 : 64;
+  h->last_tile_n = plan.tile == TILE_256 ? Tiles<T>::HUGE_BN : h->last_tile_m;
+  auto launch_medium = [&](const GemmArgs<T>& ga) {
     if (plan.tile == TILE_192)
-      return launch_tile<T, 192, 192, Tiles<T>::MEDIUM_BK, 2, 4, sizeof(T) == 4 ? 2 : 1, MS>(g, p.ta, p.tb, h->stream);
-    return launch_tile<T, 96, 96, Tiles<T>::MEDIUM_BK, 2, 2, 2, MS>(g, p.ta, p.tb, h->stream);
-  }
+      return launch_tile<T, 192, 192, Tiles<T>::MEDIUM_BK, 2, 4, sizeof(T) == 4 ? 2 : 1, MS>(ga, p.ta, p.tb, h->stream);
+    return launch_tile<T, 96, 96, Tiles<T>::MEDIUM_BK, 2, 2, 2, MS>(ga, p.ta, p.tb, h->stream);
+  };
 
-  const int bk = plan.tile == TILE_256 ? Tiles<T>::HUGE_BK : plan.tile == TILE_128 ? Tiles<T>::LARGE_BK : Tiles<T>::SMALL_BK;
+  const int bk = plan.tile == TILE_256 ? Tiles<T>::HUGE_BK : plan.tile == TILE_128 ? Tiles<T>::LARGE_BK : medium ? Tiles<T>::MEDIUM_BK : Tiles<T>::SMALL_BK;
   // K slab of one slice: whole K tiles (gemm_partial_local.hpp:174, :253).
   int64_t depth = std::max<int64_t>(1, plan.depth);
   const int64_t k_chunk = std::max<int64_t>(bk, bk * ceil_div(p.k, int64_t(bk) * depth));
   depth = std::max<int64_t>(1, ceil_div(p.k, k_chunk));
 
   // equal halves whose start stays 16-byte aligned: both sets then run the same steps (and the same K tail)
-  if (depth == 2 && plan.fused && plan.tile != TILE_256 && p.k % (2 * Mfma<T>::V) == 0 && p.k / 2 >= bk) {
+  if (depth == 2 && plan.fused && plan.tile != TILE_256 && plan.tile != TILE_192 && p.k % (2 * Mfma<T>::V) == 0 && p.k / 2 >= bk) {
     GemmArgs<T> gp = g;
     gp.k_chunk = p.k / 2;
     hipError_t e = plan.tile == TILE_128
                        ? launch_halves<T, 128, 128, Tiles<T>::LARGE_BK, Tiles<T>::LARGE_WM, 2, sizeof(T) == 4 ? 4 : 2>(
                              gp, p.ta, p.tb, h->stream)
-                       : launch_halves<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream);
+                   : plan.tile == TILE_96 ? launch_halves<T, 96, 96, Tiles<T>::MEDIUM_BK, 2, 2, 1, MS>(gp, p.ta, p.tb, h->stream)
+                                          : launch_halves<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2, 2>(gp, p.ta, p.tb, h->stream);
     h->last_kernel = SBAMD_KERNEL_SPLITK;
     h->last_depth = 2;
     h->last_k_chunk = gp.k_chunk;
+    h->last_fused = true;
     return e;
   }
   if (depth > 1) {
@@ -654,7 +663,8 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       if (slabs_dma) e = launch_dma_tile<64, 64, 32, 2, 2, 3, 3>(gp, h->stream);
     }
     if (!slabs_dma)
-      e = plan.tile == TILE_256   ? launch_huge<T>(gp, p.ta, p.tb, h->stream)
+      e = medium                  ? launch_medium(gp)
+          : plan.tile == TILE_256 ? launch_huge<T>(gp, p.ta, p.tb, h->stream)
           : plan.tile == TILE_128 ? launch_tile<T, 128, 128, Tiles<T>::LARGE_BK, Tiles<T>::LARGE_WM, 2, 2>(gp, p.ta, p.tb, h->stream)
                                   : launch_tile<T, 64, 64, Tiles<T>::SMALL_BK, 2, 2, Tiles<T>::SMALL_OCC>(gp, p.ta, p.tb, h->stream);
     if (e != hipSuccess) return e;
@@ -668,6 +678,10 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     return hipGetLastError();
   }
 
+  if (medium) {
+    h->last_kernel = SBAMD_KERNEL_MEDIUM;
+    return launch_medium(g);
+  }
   switch (plan.tile) {
     case TILE_128:
       h->last_kernel = SBAMD_KERNEL_LARGE;

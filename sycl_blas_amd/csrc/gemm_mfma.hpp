@@ -1223,11 +1223,11 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 // workgroup per compute unit).  The host checks that k splits into two equal halves of at least one K step whose start stays
 // 16-byte aligned (both sets then run the same steps, K tail included) and sets
 // g.k_chunk = k / 2.
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC>
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC, typename MS = Mfma<T>>
 __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
     gemm_mfma_halves_kernel(const GemmArgs<T> g) {
-  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB>;
-  using M = Mfma<T>;
+  using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB, MS>;
+  using M = MS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SBAMD_LDS T* smem = (SBAMD_LDS T*)smem_raw;
 
@@ -1253,7 +1253,7 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
 
   // (fp32 128 x 128 tile, A 'n', B 't': in this kernel hipcc sinks the global loads of the K step behind its last
   // matrix instructions, which it does not do for the same tile in gemm_mfma_kernel; fenced, +1-2 %)
-  GemmBody<T, BM, BN, BK, WM, WN, TA, TB, (sizeof(T) == 4 && K::MI * K::NI == 2 && !TA && TB)> body;
+  GemmBody<T, BM, BN, BK, WM, WN, TA, TB, (sizeof(T) == 4 && K::MI * K::NI == 2 && !TA && TB), MS> body;
 #pragma unroll
   for (int i = 0; i < K::MI; ++i)
 #pragma unroll

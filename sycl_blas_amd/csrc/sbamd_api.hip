@@ -180,6 +180,8 @@ int gemm_backend(sbamd_handle_t hh, char transa, char transb, int64_t m, int64_t
   h->last_kernel = -1;
   h->last_depth = 1;
   h->last_k_chunk = k;
+  h->last_tile_m = h->last_tile_n = 0;
+  h->last_fused = false;
 
   if (alpha == TScal(0)) {
     // gemm_interface.hpp:112-139.  size_c == stride_c picks a whole-buffer
@@ -400,6 +402,15 @@ int sbamd_last_splitk(sbamd_handle_t h, int64_t* depth, int64_t* k_chunk) {
   if (!depth || !k_chunk) return SBAMD_INVALID_VALUE;
   *depth = h->impl.last_depth;
   *k_chunk = h->impl.last_k_chunk;
+  return SBAMD_OK;
+}
+
+int sbamd_last_tile(sbamd_handle_t h, int* tile_m, int* tile_n, int* fused) {
+  if (!h) return SBAMD_INVALID_HANDLE;
+  if (!tile_m || !tile_n || !fused) return SBAMD_INVALID_VALUE;
+  *tile_m = h->impl.last_tile_m;
+  *tile_n = h->impl.last_tile_n;
+  *fused = h->impl.last_fused ? 1 : 0;
   return SBAMD_OK;
 }
 

@@ -23,6 +23,8 @@ struct Handle {
   int kernel_param = 0;
   int last_kernel = -1;
   int64_t last_depth = 1;    // split-K cut of the last call
+  int last_tile_m = 0, last_tile_n = 0;  // macro tile of the last fp32 / fp64 call's matrix-pipe kernel (0: none)
+  bool last_fused = false;   // both K halves inside one workgroup
   int64_t last_k_chunk = 0;
   int64_t last_trsm_diag = 0;   // how the last _trsm call was carried out
   int64_t last_trsm_panel = 0;

@@ -219,6 +219,12 @@ class SB_Handle:
         _check(self, _lib.load().sbamd_last_splitk(self._h, C.byref(depth), C.byref(chunk)))
         return depth.value, chunk.value
 
+    def last_tile(self):
+        """(tile rows, tile columns, fused) of the last fp32 / fp64 call's matrix-instruction kernel; (0, 0, False) = none."""
+        tm, tn, fused = C.c_int(), C.c_int(), C.c_int()
+        _check(self, _lib.load().sbamd_last_tile(self._h, C.byref(tm), C.byref(tn), C.byref(fused)))
+        return tm.value, tn.value, bool(fused.value)
+
     def last_trsm_launches(self):
         """(diagonal super-block launches, panel-update launches) of the last _trsm; (0, 0) = block by block."""
         diag, panel = C.c_int64(), C.c_int64()

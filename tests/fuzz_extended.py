@@ -33,7 +33,7 @@ def walk_general(h, rng, cases, log=None):
         if mode == 0:
             h.set_kernel(_lib.KERNEL_SMALL)
         elif mode == 1:
-            h.set_kernel(_lib.KERNEL_SPLITK, int(rng.choice([2, 3, 4, 5])) | (int(rng.integers(1, 4)) << 16) | (int(rng.integers(0, 2)) << 24))
+            h.set_kernel(_lib.KERNEL_SPLITK, int(rng.choice([2, 3, 4, 5])) | (int(rng.choice([1, 2, 3, 6, 7])) << 16) | (int(rng.integers(0, 2)) << 24))
         elif mode == 6:
             h.set_kernel(_lib.KERNEL_MEDIUM, int(rng.integers(0, 2)))
         else:

@@ -72,7 +72,7 @@ def test_config4_shape_sample(sb_handle):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
-@pytest.mark.parametrize("tile", [1, 2], ids=["64x64", "128x128"])
+@pytest.mark.parametrize("tile", [1, 2, 6], ids=["64x64", "128x128", "96x96"])
 def test_two_halves_in_one_workgroup(sb_handle, tile, dtype):
     # Depth 2 with both K halves inside one workgroup (parameter bit 24) must give the bits of the cube
     # route with two slabs -- (alpha*S0 + alpha*S1) + beta*C -- on interior tiles, ragged edges, odd
@@ -87,6 +87,7 @@ def test_two_halves_in_one_workgroup(sb_handle, tile, dtype):
                 verify_gemm(sb_handle, dtype, 0, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
                 assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK
                 assert sb_handle.last_splitk() == (2, k // 2)
+                assert sb_handle.last_tile() == ({1: 64, 2: 128, 6: 96}[tile],) * 2 + (True,)
         # a K whose halves would not start 16-byte aligned takes the cube route
         verify_gemm(sb_handle, dtype, 0, 1, 65, 126, 1002, "n", "t", 1.5, 0.5, 1, 1, 1)
         assert sb_handle.last_splitk()[0] == 2 and sb_handle.last_splitk()[1] != 501
@@ -98,6 +99,23 @@ def test_planner_uses_the_halves_for_a_half_filled_chip(sb_handle):
     # 1024^3 in fp64: 256 tiles of 64x64 leave three of four workgroup slots per compute unit empty.
     verify_gemm(sb_handle, np.float64, 0, 1, 1024, 1024, 1024, "n", "n", 1.5, 0.5, 1, 1, 1)
     assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK and sb_handle.last_splitk() == (2, 512)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("tile", [6, 7], ids=["96x96", "192x192"])
+def test_forced_split_on_the_medium_tiles(sb_handle, tile, dtype):
+    # K slabs through the cube on the 96 x 96 and 192 x 192 tiles (the 16x16x4 matrix instruction in fp32): every
+    # transpose, K cuts that are and are not whole K steps, ragged edges, odd leading dimensions.
+    try:
+        for depth in (2, 3, 5):
+            sb_handle.set_kernel(_lib.KERNEL_SPLITK, depth | (tile << 16))
+            for (m, n, k), ta, tb in itertools.product([(192, 192, 2048), (300, 200, 2064), (97, 388, 1000)], "nt", "nt"):
+                for alpha, beta, ldm in ((1.5, 0.5, 1), (2.0, 0.0, 3)):
+                    verify_gemm(sb_handle, dtype, 0, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
+                    assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK and sb_handle.last_splitk()[0] == depth
+                    assert sb_handle.last_tile() == ((96, 96, False) if tile == 6 else (192, 192, False))
+    finally:
+        sb_handle.set_kernel(_lib.KERNEL_AUTO)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)

@@ -15,12 +15,12 @@ import numpy as np
 from scipy.optimize import least_squares
 
 CUS = 256
-TILES = {1: (64, 64, 4), 2: (128, 128, 2), 3: (256, 128, 1)}  # the fp32 "huge" tile is 256 wide, see features()
-KERN_TILE = {2: 1, 1: 2, 5: 3}  # single-launch families -> tile
+TILES = {1: (64, 64, 4), 2: (128, 128, 2), 3: (256, 128, 1), 6: (96, 96, 2), 7: (192, 192, 1)}  # the fp32 "huge" tile is 256 wide, see features()
+KERN_TILE = {2: 1, 1: 2, 5: 3}  # single-launch families -> tile (family 9: the 96 / 192 tiles by parameter bit 0)
 
 
 def bk_of(tile, dtype):
-    return {1: 32, 2: 32, 3: 16}[tile] if dtype == "float" else {1: 16, 2: 16, 3: 16}[tile]
+    return {1: 32, 2: 32, 3: 16, 6: 32, 7: 32}[tile] if dtype == "float" else 16
 
 
 def features(dtype, tile, depth, m, n, k):
@@ -36,7 +36,7 @@ def features(dtype, tile, depth, m, n, k):
 
 
 def unpack(x):
-    return {"per_k": {1: x[0:4], 2: x[4:6], 3: x[6:7]}, "t_single": x[7], "t_split": x[8], "bw": x[9], "c_depth": x[10]}
+    return {"per_k": {1: x[0:4], 2: x[4:6], 3: x[6:7], 6: x[11:13], 7: x[13:14]}, "t_single": x[7], "t_split": x[8], "bw": x[9], "c_depth": x[10]}
 
 
 def model(p, dtype, tile, depth, m, n, k):
@@ -68,13 +68,16 @@ def main(path):
             continue
         if kern in KERN_TILE:
             tile, depth = KERN_TILE[kern], 1
+        elif kern == 9:
+            tile, depth = (7 if depth & 1 else 6), 1
         elif kern != 3:
             continue
         data.append((dt, tile, depth, m, n, k, us))
     dtype = data[0][0]
-    x0 = np.array([0.035, 0.041, 0.057, 0.074, 0.078, 0.146, 0.12, 1.5, 5.0, 3.0, 0.03])
+    x0 = np.array([0.035, 0.041, 0.057, 0.074, 0.078, 0.146, 0.12, 1.5, 5.0, 3.0, 0.03, 0.04, 0.075, 0.135])
     if dtype == "double":
         x0[:7] *= 1.8
+        x0[11:] *= 1.8
 
     def resid(x):
         p = unpack(x)
@@ -87,6 +90,8 @@ def main(path):
     print("small_k = {" + ", ".join(f"{v:.4f}" for v in p["per_k"][1]) + "}")
     print("large_k = {" + ", ".join(f"{v:.4f}" for v in p["per_k"][2]) + "}")
     print("huge_k  = {" + ", ".join(f"{v:.4f}" for v in p["per_k"][3]) + "}")
+    print("medium_k = {" + ", ".join(f"{v:.4f}" for v in p["per_k"][6]) + "}")
+    print("wide_k  = {" + ", ".join(f"{v:.4f}" for v in p["per_k"][7]) + "}")
     print(f"t_single = {p['t_single']:.2f} us, t_split = {p['t_split']:.2f} us, bw = {p['bw']:.2f} TB/s, "
           f"c_depth = {p['c_depth']:.4f} us")
     by = collections.defaultdict(list)
@@ -105,7 +110,7 @@ def main(path):
               f"{regrets[int(len(regrets)*0.9)]:.3f}, max {regrets[-1]:.3f}")
     # halves_factor of gemm_dispatch.hpp (estimate_us with fused = true): measured time of the fused launch
     # over the model's time for the two sets as two resident workgroups per tile, where the planner may use it
-    for tile in (1, 2):
+    for tile in (1, 2, 6):
         ratios = []
         for dt, t, m, n, k, us in fused_rows:
             bm, bn, occ = TILES[t]
