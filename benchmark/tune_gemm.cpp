@@ -104,6 +104,7 @@ void tune(sbamd_handle_t h, char ta, char tb, int64_t m, int64_t k, int64_t n, i
                            SBAMD_KERNEL_SPLITK, depth | (tile << 16), false});
         }
       // both halves of K in one workgroup (falls back to the cube route when K does not split into whole K steps)
+      cands.push_back({"quarters 32x32 (four K quarters per workgroup)", SBAMD_KERNEL_SPLITK, 4 | (4 << 16) | (1 << 24), false});
       for (int tile : {1, 2, 6})
         cands.push_back({std::string("halves ") + tile_names[tile] + " (two K halves per workgroup)", SBAMD_KERNEL_SPLITK,
                          2 | (tile << 16) | (1 << 24), false});

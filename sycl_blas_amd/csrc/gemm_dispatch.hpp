@@ -162,12 +162,14 @@ hipError_t launch_stream(const GemmArgs<T>& g, bool ta, bool tb, int cus, hipStr
 }
 
 // Both halves of K in one workgroup (gemm_mfma_halves_kernel); g.k_chunk = k / 2.
-template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB, typename MS = Mfma<T>>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, bool TA, bool TB, typename MS = Mfma<T>, int SETS = 2>
 hipError_t launch_halves_one(const GemmArgs<T>& g, hipStream_t stream) {
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB, MS>;
-  auto kernel = gemm_mfma_halves_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC, MS>;
-  constexpr size_t lds = 2 * K::LDS_BYTES;
-  static_assert(lds <= 160 * 1024, "two sets of buffers must fit the LDS");
+  auto kernel = gemm_mfma_halves_kernel<T, BM, BN, BK, WM, WN, TA, TB, OCC, MS, SETS>;
+  // the sets' staging buffers, reused for the hand-over of SETS - 1 sets of accumulators
+  constexpr size_t handover = size_t(SETS - 1) * BM * BN * sizeof(T);
+  constexpr size_t lds = SETS * K::LDS_BYTES > handover ? SETS * K::LDS_BYTES : handover;
+  static_assert(lds <= 160 * 1024, "the sets' buffers must fit the LDS");
   static PerDeviceOnce lds_limit;
   hipError_t e = lds_limit.run([&] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -176,20 +178,20 @@ hipError_t launch_halves_one(const GemmArgs<T>& g, hipStream_t stream) {
   if (e != hipSuccess) return e;
   const int64_t grid = int64_t(g.tiles_m) * g.tiles_n * g.batch;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(2 * K::NT), lds, stream, g);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(SETS * K::NT), lds, stream, g);
   return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, typename MS = Mfma<T>>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int OCC, typename MS = Mfma<T>, int SETS = 2>
 hipError_t launch_halves(GemmArgs<T> g, bool ta, bool tb, hipStream_t stream) {
   g.tiles_m = int32_t(ceil_div(g.m, BM));
   g.tiles_n = int32_t(ceil_div(g.n, BN));
   if (ta) {
-    return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, true, MS>(g, stream)
-              : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, false, MS>(g, stream);
+    return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, true, MS, SETS>(g, stream)
+              : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, true, false, MS, SETS>(g, stream);
   }
-  return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, true, MS>(g, stream)
-            : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, false, MS>(g, stream);
+  return tb ? launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, true, MS, SETS>(g, stream)
+            : launch_halves_one<T, BM, BN, BK, WM, WN, OCC, false, false, MS, SETS>(g, stream);
 }
 
 // The biggest tile: 256 x 256 (float) / 256 x 128 (double), eight waves as 4 (M) x 2 (N).
@@ -341,6 +343,10 @@ struct CostModel<float> {
   // fit's median over the sweep; 128 x 128 from long launches (8192^3 0.960, 6144^3 0.966, 4096^3 0.976,
   // 2048 x 2048 x 16384 0.952)
   static constexpr double halves_factor[3] = {0.981, 0.965, 0.98};  // third: the 96 x 96 tile
+  // four K quarters in one workgroup of four one-wave sets on the 32 x 32 tile: microseconds per unit of a
+  // quarter's K and per round of workgroups over the units, and the launch's fixed part (512^3: 7.3 us,
+  // 512 x 512 x 2048: 16.5; 640^3, two rounds: 11.2; 1024 x 1024 x 512, four rounds: 16.0)
+  static constexpr double quarter_k = 0.0241, quarter_over = 4.2;
   static constexpr CostOverheads over = {4.71, 7.43, 5.63e6, 0.0497};
 };
 template <>
@@ -355,6 +361,8 @@ struct CostModel<double> {
   static constexpr double medium_k[2] = {0.0705, 0.1360};
   static constexpr double wide_k[1] = {0.2600};
   static constexpr double halves_factor[3] = {0.800, 0.998, 0.90};
+  // (512^3: 9.8 us, 512 x 512 x 2048: 26.2; 640^3: 16.6; 768^3, three rounds: 25.5)
+  static constexpr double quarter_k = 0.0428, quarter_over = 4.3;
   static constexpr CostOverheads over = {6.16, 6.81, 6.25e6, 0.0438};
 };
 
@@ -462,7 +470,8 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
   // with more tiles it loses to the plain launch.
   for (int tile : {TILE_64, TILE_128, TILE_96}) {
     const int edge = tile == TILE_128 ? 128 : tile == TILE_96 ? 96 : 64, occ = tile == TILE_64 ? 4 : 2;
-    if (k % (2 * Mfma<T>::V) != 0 || k < 512) continue;  // equal, vector-aligned halves; short K: the hand-over is not free
+    // equal, vector-aligned halves of at least eight K steps each (short K: the hand-over is not free)
+    if (k % (2 * Mfma<T>::V) != 0 || k < 16 * Tiles<T>::SMALL_BK) continue;
     // 64 x 64: only where the tiles alone leave at least half of a unit's workgroup slots empty (the measured
     // factor is the gain of doubling the wavefronts of an under-filled unit; on a full unit there is none).
     // 128 x 128: any tile count -- a workgroup of two sets has a unit to itself, which also evens out tile counts
@@ -474,6 +483,14 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
     // cube has to win 10 %): the cut is always in two equal halves, whatever the device, and costs neither a
     // second launch nor a trip through memory
     if (us < (tile == TILE_128 ? 0.98 : 0.96) * best_us && us < chosen_us) chosen_us = us, chosen = {tile, 2, true};
+  }
+  // Four quarters of K inside one workgroup of four one-wave sets on the 32 x 32 tile: a product too small to fill
+  // the chip with 64 x 64 tiles and too short for a cut through the cube to pay for its second launch, spread over
+  // four times as many wavefronts in ONE launch (512^3: fp64 13.8 -> 9.8 us, fp32 11.1 -> 7.3).
+  if (k % (4 * Mfma<T>::V) == 0 && k >= 256) {
+    const int64_t rounds = ceil_div(ceil_div(m, 32) * ceil_div(n, 32), int64_t(cus));
+    const double us = CostModel<T>::quarter_over + double(rounds) * CostModel<T>::quarter_k * double(k / 4);
+    if (us < 0.96 * chosen_us) chosen_us = us, chosen = {TILE_32, 4, true};
   }
   return chosen;
 }
@@ -587,15 +604,20 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
       plan = {(h->kernel_param & 1) ? TILE_192 : TILE_96, 1};
       break;
     case SBAMD_KERNEL_SPLITK:
-      if (tile_cuts_k(pin_tile)) plan.tile = pin_tile;
+      if (tile_cuts_k(pin_tile) || (pin_tile == TILE_32 && pin_fused)) plan.tile = pin_tile;
       else if (!tile_cuts_k(plan.tile)) plan.tile = TILE_64;
       if (pin_depth > 0) plan.depth = pin_depth;
       plan.fused = pin_fused;
-      if (pin_fused) plan.depth = 2;
+      if (pin_fused) plan.depth = plan.tile == TILE_32 ? 4 : 2;  // the 32 x 32 tile: four quarters of K in one workgroup
       break;
     default: return hipErrorInvalidValue;
   }
-  if (p.batch != 1 || !tile_cuts_k(plan.tile)) plan.depth = 1;
+  // four quarters of K in a workgroup of four one-wave sets on the 32 x 32 tile: equal, vector-aligned quarters of
+  // at least one K step; anything else pinned that way takes the cube route on the 64 x 64 tile
+  const bool quarters = plan.tile == TILE_32 && plan.fused && plan.depth == 4 && p.batch == 1 &&
+                        p.k % (4 * Mfma<T>::V) == 0 && p.k / 4 >= Tiles<T>::TINY_BK;
+  if (plan.tile == TILE_32 && plan.fused && !quarters) plan = {TILE_64, p.batch == 1 ? 4 : 1, false};
+  if (p.batch != 1 || (!tile_cuts_k(plan.tile) && !quarters)) plan.depth = 1;
   if (plan.tile == TILE_NAIVE) {
     h->last_kernel = SBAMD_KERNEL_NAIVE;
     // pinned: one element per lane.  Chosen for a batch of very small items: its 4 x 4 register-block form once
@@ -603,6 +625,16 @@ hipError_t run_gemm_real(Handle* h, const Problem<T, T>& p) {
     // the block form leaves too few lanes per item to keep their loads on shared cache lines (fp32 4^3: 64 -> 128 us)
     if (h->kernel_override == SBAMD_KERNEL_NAIVE || p.m * p.n * int64_t(sizeof(T)) < 512) return launch_naive<T>(g, p.ta, p.tb, h->stream);
     return launch_block<T>(g, p.ta, p.tb, h->stream);
+  }
+  if (quarters) {
+    GemmArgs<T> gp = g;
+    gp.k_chunk = p.k / 4;
+    h->last_kernel = SBAMD_KERNEL_SPLITK;
+    h->last_depth = 4;
+    h->last_k_chunk = gp.k_chunk;
+    h->last_tile_m = h->last_tile_n = 32;
+    h->last_fused = true;
+    return launch_halves<T, 32, 32, Tiles<T>::TINY_BK, 1, 1, 2, Mfma<T>, 4>(gp, p.ta, p.tb, h->stream);
   }
   if (plan.tile == TILE_32) {
     h->last_kernel = SBAMD_KERNEL_TINY;

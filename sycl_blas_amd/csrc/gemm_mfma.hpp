@@ -1223,15 +1223,18 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 // workgroup per compute unit).  The host checks that k splits into two equal halves of at least one K step whose start stays
 // 16-byte aligned (both sets then run the same steps, K tail included) and sets
 // g.k_chunk = k / 2.
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC, typename MS = Mfma<T>>
-__global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
+// SETS = 4 is the same with four sets on four quarters of K, summed in slab order
+//     ((alpha * acc0 + alpha * acc1) + alpha * acc2) + alpha * acc3,  then + beta * C:
+// the cube route's result for four slabs.
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int OCC, typename MS = Mfma<T>, int SETS = 2>
+__global__ void __launch_bounds__(SETS * WM* WN * 64, OCC)
     gemm_mfma_halves_kernel(const GemmArgs<T> g) {
   using K = GemmTile<T, BM, BN, BK, WM, WN, TA, TB, MS>;
   using M = MS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SBAMD_LDS T* smem = (SBAMD_LDS T*)smem_raw;
 
-  const int half = threadIdx.x / K::NT;  // wave-uniform: NT is a multiple of 64
+  const int half = threadIdx.x / K::NT;  // which set: wave-uniform, NT is a multiple of 64
   const int tid = threadIdx.x - half * K::NT;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1276,11 +1279,12 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
     body.run_edge(g, a, b, m0, n0, k_begin, k_end, mine, tid, a_mn, b_mn);
   }
 
-  // hand-over: [wave][subtile][register][lane], lane fastest
+  // hand-over: [set - 1][wave][subtile][register][lane], lane fastest
   const T alpha = g.alpha, beta = g.beta;
+  constexpr int SET_SLOTS = WM * WN * K::MI * K::NI * M::NACC * 64;
   __syncthreads();
-  SBAMD_LDS T* slot = smem + (wave * K::MI * K::NI * M::NACC) * 64 + lane;
-  if (half == 1) {
+  SBAMD_LDS T* slot = smem + (half > 0 ? (half - 1) * SET_SLOTS : 0) + (wave * K::MI * K::NI * M::NACC) * 64 + lane;
+  if (half >= 1) {
 #pragma unroll
     for (int i = 0; i < K::MI; ++i)
 #pragma unroll
@@ -1289,7 +1293,7 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
         for (int r = 0; r < M::NACC; ++r) slot[((i * K::NI + j) * M::NACC + r) * 64] = alpha * body.acc[i][j][r];
   }
   __syncthreads();
-  if (half == 1) return;
+  if (half >= 1) return;
   store_tiles<K::MI, K::NI, M::NACC, T>(
       !g.beta_zero, beta,
       [&](int i, int j, int r) -> T* {
@@ -1298,8 +1302,10 @@ __global__ void __launch_bounds__(2 * WM* WN * 64, OCC)
         return (mm < g.m && nn < g.n) ? c + mm + nn * g.ldc : nullptr;
       },
       [&](int i, int j, int r) -> T {
-        const T first = alpha * body.acc[i][j][r];
-        return first + slot[((i * K::NI + j) * M::NACC + r) * 64];
+        T sum = alpha * body.acc[i][j][r];
+#pragma unroll
+        for (int other = 0; other < SETS - 1; ++other) sum = sum + slot[other * SET_SLOTS + ((i * K::NI + j) * M::NACC + r) * 64];
+        return sum;
       },
       [](const T* p) -> T { return *p; }, [](T* p, T v) { *p = v; });
 }

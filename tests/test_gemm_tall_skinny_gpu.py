@@ -95,6 +95,26 @@ def test_two_halves_in_one_workgroup(sb_handle, tile, dtype):
         sb_handle.set_kernel(_lib.KERNEL_AUTO)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=lambda d: np.dtype(d).name)
+def test_four_quarters_in_one_workgroup(sb_handle, dtype):
+    # Depth 4 with the four K quarters inside one workgroup of four one-wave sets on the 32 x 32 tile must give the
+    # bits of the cube route with four slabs -- ((alpha*S0 + alpha*S1) + alpha*S2) + alpha*S3, then + beta*C.
+    sb_handle.set_kernel(_lib.KERNEL_SPLITK, 4 | (4 << 16) | (1 << 24))
+    try:
+        for (m, n, k), ta, tb in itertools.product([(32, 32, 128), (128, 256, 512), (200, 130, 1024), (7, 9, 192),
+                                                    (257, 63, 640), (100, 132, 1008), (64, 64, 144)], "nt", "nt"):
+            for alpha, beta, ldm in ((1.5, 0.5, 1), (2.0, 0.0, 3)):
+                verify_gemm(sb_handle, dtype, 0, 1, m, n, k, ta, tb, alpha, beta, ldm, ldm, ldm)
+                assert sb_handle.last_kernel() == _lib.KERNEL_SPLITK
+                assert sb_handle.last_splitk() == (4, k // 4)
+                assert sb_handle.last_tile() == (32, 32, True)
+        # quarters that would not start 16-byte aligned take the cube route
+        verify_gemm(sb_handle, dtype, 0, 1, 65, 126, 1004, "n", "t", 1.5, 0.5, 1, 1, 1)
+        assert sb_handle.last_splitk()[0] == 4 and sb_handle.last_tile() == (64, 64, False)
+    finally:
+        sb_handle.set_kernel(_lib.KERNEL_AUTO)
+
+
 def test_planner_uses_the_halves_for_a_half_filled_chip(sb_handle):
     # 1024^3 in fp64: 256 tiles of 64x64 leave three of four workgroup slots per compute unit empty.
     verify_gemm(sb_handle, np.float64, 0, 1, 1024, 1024, 1024, "n", "n", 1.5, 0.5, 1, 1, 1)

@@ -8,6 +8,7 @@ how far the plan the fitted model would pick is from the best measured candidate
 """
 import collections
 import csv
+import os
 import math
 import sys
 
@@ -15,6 +16,9 @@ import numpy as np
 from scipy.optimize import least_squares
 
 CUS = 256
+# The workgroups of a last, partly filled round do not spread evenly over the units (they go where slots free up
+# first): `rem` leftover workgroups per unit cost what TAIL * rem resident ones do.
+TAIL = int(os.environ.get("TAIL", "1"))
 TILES = {1: (64, 64, 4), 2: (128, 128, 2), 3: (256, 128, 1), 6: (96, 96, 2), 7: (192, 192, 1)}  # the fp32 "huge" tile is 256 wide, see features()
 KERN_TILE = {2: 1, 1: 2, 5: 3}  # single-launch families -> tile (family 9: the 96 / 192 tiles by parameter bit 0)
 
@@ -42,7 +46,7 @@ def unpack(x):
 def model(p, dtype, tile, depth, m, n, k):
     occ, full, rem, k_chunk = features(dtype, tile, depth, m, n, k)
     per_k = p["per_k"][tile]
-    us = k_chunk * (full * per_k[occ - 1] + (per_k[rem - 1] if rem else 0.0))
+    us = k_chunk * (full * per_k[occ - 1] + (per_k[(min(occ, TAIL * rem) if full else rem) - 1] if rem else 0.0))
     size = 4 if dtype == "float" else 8
     if depth > 1:
         us += p["t_split"] + 2.0 * m * n * depth * size / (p["bw"] * 1e6) + p["c_depth"] * depth
@@ -61,7 +65,8 @@ def main(path):
         m, k, n, kern, tile, depth = int(m), int(k), int(n), int(kern), int(tile), int(depth)
         us = float(ms) * 1e3
         if fused:
-            fused_rows.append((dt, tile, m, n, k, us))
+            if tile in TILES:  # (the four-quarters form on the 32 x 32 tile has constants of its own)
+                fused_rows.append((dt, tile, m, n, k, us))
             continue
         if kern == 0:
             auto[(m, n, k)] = us
@@ -122,7 +127,7 @@ def main(path):
             bk = bk_of(t, dt)
             k_chunk = bk * math.ceil(k / (bk * 2))
             per_k = p["per_k"][t]
-            base = k_chunk * (full * per_k[occ - 1] + (per_k[rem - 1] if rem else 0.0))
+            base = k_chunk * (full * per_k[occ - 1] + (per_k[(min(occ, TAIL * rem) if full else rem) - 1] if rem else 0.0))
             ratios.append((us - p["t_single"]) / base)
         if ratios:
             ratios.sort()

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
   if (sbamd_malloc(h, &a, size_t(m) * k * bs * es) || sbamd_malloc(h, &b, size_t(k) * n * bs * es) || sbamd_malloc(h, &c, size_t(m) * n * bs * es)) return 1;
   if (sbamd_fill_uniform(h, a, m * k * bs, f64, 11, -1.0, 1.0) || sbamd_fill_uniform(h, b, k * n * bs, f64, 12, -1.0, 1.0)) return 1;
   if (argc > 6 && sbamd_set_kernel(h, std::atoi(argv[6]), argc > 7 ? std::atoi(argv[7]) : 0) != SBAMD_OK) return 1;
-  for (int i = 0; i < 12; ++i) {
+  auto call = [&]() {
     int st;
     if (f64)
       st = bs == 1 ? sbamd_dgemm(h, 'n', 'n', m, n, k, 1.0, (const double*)a, m, (const double*)b, k, 0.0, (double*)c, m)
@@ -30,9 +30,25 @@ int main(int argc, char** argv) {
       st = bs == 1 ? sbamd_sgemm(h, 'n', 'n', m, n, k, 1.0f, (const float*)a, m, (const float*)b, k, 0.0f, (float*)c, m)
                    : sbamd_sgemm_strided_batched(h, 'n', 'n', m, n, k, 1.0f, (const float*)a, m, m * k, (const float*)b, k, k * n, 0.0f,
                                                  (float*)c, m, m * n, bs);
-    if (st != SBAMD_OK) return std::printf("status %d: %s\n", st, sbamd_status_string(st)), 2;
-  }
+    return st;
+  };
+  for (int i = 0; i < 12; ++i)
+    if (int st = call(); st != SBAMD_OK) return std::printf("status %d: %s\n", st, sbamd_status_string(st)), 2;
   if (sbamd_wait(h) != SBAMD_OK) return 3;
+  if (std::getenv("ONE_FAMILY_TIME")) {  // best of five loops of 200 calls
+    double best = 1e30;
+    for (int round = 0; round < 5; ++round) {
+      sbamd_event_t e0 = nullptr, e1 = nullptr;
+      float ms = 0;
+      sbamd_event_record(h, &e0);
+      for (int i = 0; i < 200; ++i) call();
+      sbamd_event_record(h, &e1);
+      if (sbamd_wait(h) != SBAMD_OK || sbamd_event_elapsed_ms(e0, e1, &ms) != SBAMD_OK) return 3;
+      sbamd_event_destroy(e0), sbamd_event_destroy(e1);
+      if (ms / 200 < best) best = ms / 200;
+    }
+    std::printf("%.2f us per call  ", best * 1e3);
+  }
   int64_t depth = 0, chunk = 0;
   sbamd_last_splitk(h, &depth, &chunk);
   std::printf("kernel %d depth %lld chunk %lld\n", sbamd_last_kernel(h), (long long)depth, (long long)chunk);

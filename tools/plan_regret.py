@@ -75,6 +75,12 @@ def main():
     print(f"{os.path.basename(path)}: {len(rows)} shapes, planner = {'sources as they are (plan_probe)' if probe else 'library at sweep time (auto line)'}"
           f"{', ' + str(cus) + ' compute units' if probe else ''}; {missing} choices not among the candidates")
     print(f"  time of the chosen candidate / best candidate: median {r[len(r) // 2]:.3f}, 90th pct {r[int(len(r) * 0.9)]:.3f}, max {r[-1]:.3f}")
+    for floor in (20.0, 50.0):
+        big = [x[0] for x in rows if x[5] * 1e3 >= floor]
+        if big:
+            print(f"  shapes whose best candidate takes at least {floor:.0f} us ({len(big)}): median {big[len(big) // 2]:.3f}, 90th pct {big[int(len(big) * 0.9)]:.3f}, max {big[-1]:.3f}")
+    lost = sorted((x[3] - x[5]) * 1e3 for x in rows)
+    print(f"  microseconds lost to the best candidate: median {lost[len(lost) // 2]:.2f}, 90th pct {lost[int(len(lost) * 0.9)]:.2f}, max {lost[-1]:.1f}")
     for ratio, shape, pick, t, best_id, tb in rows:
         if ratio >= show:
             print(f"    {shape[0]:5d} x {shape[1]:5d} x {shape[2]:5d}: chose {pick[0]}x{pick[1]} depth {pick[2]}{' fused' if pick[3] else ''} {t * 1e3:8.1f} us, "
