@@ -347,7 +347,9 @@ struct CostModel<float> {
   // quarter's K and per round of workgroups over the units, and the launch's fixed part (512^3: 7.3 us,
   // 512 x 512 x 2048: 16.5; 640^3, two rounds: 11.2; 1024 x 1024 x 512, four rounds: 16.0)
   static constexpr double quarter_k = 0.0241, quarter_over = 4.2;
-  static constexpr CostOverheads over = {4.71, 7.43, 5.63e6, 0.0497};
+  // (the fit's 7.4 us for the two launches of a cut comes mostly from long slabs; cuts of launches under 15 us
+  // measure 5.5-6.6 us, and the reference suites' small shapes choose better with 6.2)
+  static constexpr CostOverheads over = {4.71, 6.2, 5.63e6, 0.0497};
 };
 template <>
 struct CostModel<double> {
@@ -487,9 +489,12 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
   // Four quarters of K inside one workgroup of four one-wave sets on the 32 x 32 tile: a product too small to fill
   // the chip with 64 x 64 tiles and too short for a cut through the cube to pay for its second launch, spread over
   // four times as many wavefronts in ONE launch (512^3: fp64 13.8 -> 9.8 us, fp32 11.1 -> 7.3).
-  if (k % (4 * Mfma<T>::V) == 0 && k >= 256) {
+  // (not for a sliver of C: its 32 x 32 tiles would be mostly padding)
+  if (k % (4 * Mfma<T>::V) == 0 && k >= 128 && m >= 32 && n >= 32) {
     const int64_t rounds = ceil_div(ceil_div(m, 32) * ceil_div(n, 32), int64_t(cus));
-    const double us = CostModel<T>::quarter_over + double(rounds) * CostModel<T>::quarter_k * double(k / 4);
+    // (a further round of workgroups overlaps the one before it: it adds 0.85 of a round -- fp64 768^3, three
+    // rounds: 25.5 us; 640^3, two: 16.6)
+    const double us = CostModel<T>::quarter_over + (1.0 + 0.85 * double(rounds - 1)) * CostModel<T>::quarter_k * double(k / 4);
     if (us < 0.96 * chosen_us) chosen_us = us, chosen = {TILE_32, 4, true};
   }
   return chosen;

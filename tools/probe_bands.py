@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """What one rank of the strong-scaling schedule multiplies, timed on ONE GPU: for 2, 4 and 8 ranks the band
 GEMMs of rank 0 (sbamd_dist_band_widths over its n / ranks columns, or --bands equal bands) back to back through the
-raw C ABI, against the share of the whole product's time an ideal split would take.  The multi-GPU projection in
-DESIGN.md adds the link time to these.   usage: python tools/probe_bands.py [f32|f64] [size] [bands]"""
+raw C ABI, against the share of the whole product's time an ideal split would take.  A multi-GPU projection
+adds the link time to these.   usage: python tools/probe_bands.py [f32|f64] [size] [bands]"""
 import ctypes as C
 import os
 import sys

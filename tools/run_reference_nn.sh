@@ -26,5 +26,5 @@ cat benchmark/config_csv/$SUITE/*.csv | grep -v "^#" | sort -u | while IFS=, rea
   timeout -k 10 60 benchmark/tune_gemm $m $k $n 1 20 --trans=nn --dtype=float --csv=$out/tune_f32.csv >> $out/tune_f32.log 2>&1 || { echo "tune failed $m $k $n"; exit 1; }
 done
 echo "tuner done"
-python3 tools/sweep_summary.py $out/tune_f32.csv > $out/planner_vs_best_f32.txt
-tail -1 $out/planner_vs_best_f32.txt
+python3 tools/plan_regret.py $out/tune_f32.csv --list 1.06 > $out/planner_vs_best_f32.txt
+head -5 $out/planner_vs_best_f32.txt
