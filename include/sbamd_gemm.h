@@ -103,10 +103,11 @@ const char* sbamd_last_error(sbamd_handle_t h);
 /* Pin a kernel family (SBAMD_KERNEL_*); `param` is family specific.
  * Split-K: bits 0-15 = cube depth (0 = derive from the compute-unit count as
  * src/operations/blas3/gemm_partial_local.hpp:191-199 does), bits 16-23 = tile of
- * the partial products (0 = automatic, 1 = 64x64, 2 = 128x128, 3 = the biggest tile), bit 24 = keep
- * both halves of K (depth 2) inside one workgroup of the 64x64 / 128x128 tile instead of going through
- * the cube (same result as the cube route with two slabs; needs K to split into two equal halves whose
- * start stays 16-byte aligned, else the cube route runs).
+ * the partial products (0 = automatic, 1 = 64x64, 2 = 128x128, 3 = the biggest tile, 6 = 96x96,
+ * 7 = 192x192; 4 = 32x32 together with bit 24 only), bit 24 = keep the slabs inside ONE workgroup
+ * instead of going through the cube: both halves of K (depth 2) on the 64x64 / 128x128 / 96x96 tile,
+ * the four quarters of K (depth 4) on the 32x32 tile (same result as the cube route with two / four
+ * slabs; needs K to split into equal parts whose start stays 16-byte aligned, else the cube route runs).
  * SBAMD_KERNEL_SMALL: bit 0 = keep the register-staged kernel where the direct-to-LDS one would run
  * (fp32, A 'n', B 't'; same bits either way -- a switch for A/B timing).
  * 16-bit entry points: SBAMD_KERNEL_HUGE / SBAMD_KERNEL_LARGE are the 256x256 / 128x128 tiles of the
