@@ -2,7 +2,7 @@
 // process, interleaved over rounds, on uniform random bf16 operands, and checks each
 // against the 128x128 kernel of the library bit for bit.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Isycl_blas_amd/csrc tools/bf16_lab.hip -o tools/bin/bf16_lab
-//   tools/bin/bf16_lab [n=8192] [rounds=5] [trans=nn]
+//   tools/bin/bf16_lab [n=8192] [rounds=5] [trans=nn] [ld_pad=0]      (ld_pad: leading dimension of A and B = n + ld_pad)
 #include <cmath>
 #include <cstdio>
 #include <algorithm>
@@ -66,11 +66,12 @@ int main(int argc, char** argv) {
   const int n = argc > 1 ? std::atoi(argv[1]) : 8192;
   const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
   const std::string trans = argc > 3 ? argv[3] : "nn";
-  const size_t count = size_t(n) * n;
-  std::vector<uint16_t> host(count);
+  const int ld_pad = argc > 4 ? std::atoi(argv[4]) : 0;
+  const size_t count = size_t(n) * n, count_ab = size_t(n + ld_pad) * n;
+  std::vector<uint16_t> host(count_ab);
   uint64_t s = 88172645463325252ull;
   auto fill = [&]() {
-    for (size_t i = 0; i < count; ++i) {
+    for (size_t i = 0; i < count_ab; ++i) {
       s ^= s << 13, s ^= s >> 7, s ^= s << 17;
       const float f = float(double(s >> 11) / double(1ull << 53) * 2.0 - 1.0);  // uniform [-1, 1)
       uint32_t bits;
@@ -80,19 +81,20 @@ int main(int argc, char** argv) {
   };
   uint16_t *a, *b;
   float *c, *cref;
-  CHECK(hipMalloc(&a, count * 2));
-  CHECK(hipMalloc(&b, count * 2));
+  CHECK(hipMalloc(&a, count_ab * 2));
+  CHECK(hipMalloc(&b, count_ab * 2));
   CHECK(hipMalloc(&c, count * 4));
   CHECK(hipMalloc(&cref, count * 4));
   fill();
-  CHECK(hipMemcpy(a, host.data(), count * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(a, host.data(), count_ab * 2, hipMemcpyHostToDevice));
   fill();
-  CHECK(hipMemcpy(b, host.data(), count * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(b, host.data(), count_ab * 2, hipMemcpyHostToDevice));
 
   GemmArgs16<float> g{};
   g.a = a, g.b = b, g.c = c;
   g.m = g.n = g.k = n;
-  g.lda = g.ldb = g.ldc = n;
+  g.lda = g.ldb = n + ld_pad;
+  g.ldc = n;
   g.batch = 1;
   g.vec_a = g.vec_b = 1;
   g.alpha = 1.0f, g.beta = 0.0f, g.beta_zero = 1;
