@@ -407,70 +407,109 @@ def main():
         if args.one_rank_rccl:
             want = "rccl"
             os.environ["SBAMD_DIST_PREFER"] = "rccl"
-        if gather and want in ("auto", "mesh"):
-            try:
-                flags = _lib.DIST_MESH if args.rehearse else (_lib.DIST_MESH | _lib.DIST_RCCL)
-                native = Communicator(handle, rank, world, torch_allgather(dist), flags)
-                window = native.register(ops.c)
-                ok = True
-            except DistError as exc:
-                ok, extras["mesh_setup_error"] = False, str(exc)
-            if agree(ok):
-                transport = "mesh"
-            else:
-                if native is not None:
-                    native.close()
-                native, window = None, -1
-        if gather and native is None and want in ("auto", "rccl") and not args.rehearse:
-            try:
-                if want == "rccl":
-                    os.environ["SBAMD_DIST_PREFER"] = "rccl"
-                native = Communicator(handle, rank, world, torch_allgather(dist), _lib.DIST_RCCL)
-                ok = True
-            except DistError as exc:
-                ok, extras["rccl_setup_error"] = False, str(exc)
-            if agree(ok):
-                transport = "rccl"
-            else:
-                if native is not None:
-                    native.close()
-                native = None
-        if gather and native is None:
-            transport = "torch"
+        # a peer that never answers must end a device-side wait within seconds, not hang the run
+        os.environ.setdefault("SBAMD_DIST_TIMEOUT_MS", "5000")
+        state = {"native": None, "window": -1, "transport": "none", "bands": 1, "my_cols": []}
 
-        if transport == "mesh":
-            # rank r owns the columns split_range(gn, world, r), multiplied in bands that shrink towards the end
-            my0, my1 = split_range(gn, world, rank)
-            widths = band_widths(my1 - my0, args.bands, world)
-            bands = len(widths)
-            my_cols = []
-            for w in widths:
-                my_cols.append((my0, my0 + w))
-                my0 += w
-        else:
-            bands = args.bands or pick_bands(world, gm, gn, gk)
-            if gn % (bands * world):
-                raise SystemExit(f"--size must be divisible by bands * ranks = {bands * world}")
-            w = gn // bands // world
-            my_cols = [(bi * (gn // bands) + rank * w, bi * (gn // bands) + (rank + 1) * w) for bi in range(bands)]
+        def close_native():
+            if state["native"] is not None:
+                try:
+                    state["native"].close()
+                except DistError:
+                    pass
+            state["native"], state["window"] = None, -1
+
+        def set_up(candidate):
+            """Create the communicator of one transport; every rank learns whether all of them succeeded."""
+            ok = True
+            try:
+                if candidate == "mesh":
+                    flags = _lib.DIST_MESH if args.rehearse else (_lib.DIST_MESH | _lib.DIST_RCCL)
+                    state["native"] = Communicator(handle, rank, world, torch_allgather(dist), flags)
+                    state["window"] = state["native"].register(ops.c)
+                elif candidate == "rccl":
+                    if want == "rccl":
+                        os.environ["SBAMD_DIST_PREFER"] = "rccl"
+                    state["native"] = Communicator(handle, rank, world, torch_allgather(dist), _lib.DIST_RCCL)
+            except DistError as exc:
+                ok, extras[f"{candidate}_setup_error"] = False, str(exc)
+            if not agree(ok):
+                close_native()
+                return False
+            state["transport"] = candidate
+            if candidate == "mesh":
+                # rank r owns the columns split_range(gn, world, r), multiplied in bands that shrink towards the end
+                my0, my1 = split_range(gn, world, rank)
+                widths = band_widths(my1 - my0, args.bands, world)
+                state["bands"], state["my_cols"] = len(widths), []
+                for w in widths:
+                    state["my_cols"].append((my0, my0 + w))
+                    my0 += w
+            else:
+                nb = args.bands or pick_bands(world, gm, gn, gk)
+                if gn % (nb * world):
+                    raise SystemExit(f"--size must be divisible by bands * ranks = {nb * world}")
+                w = gn // nb // world
+                state["bands"] = nb
+                state["my_cols"] = [(bi * (gn // nb) + rank * w, bi * (gn // nb) + (rank + 1) * w) for bi in range(nb)]
+            return True
+
+        def c_digest_agrees():
+            digest = ops.tc_t.view(torch.int32 if args.dtype == "f32" else torch.int64).sum(dtype=torch.int64).reshape(1)
+            lo, hi = digest.clone(), digest.clone()
+            if args.rehearse:
+                lo, hi = lo.cpu(), hi.cpu()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            return bool(lo.item() == hi.item())
+
+        def proves_itself():
+            """One untimed step of the chosen transport before anything is timed: no wait for a peer timed out on any
+            rank and every rank holds the same C.  A transport that fails here is dropped for the next one."""
+            ok = True
+            try:
+                step()
+                if state["native"] is not None:
+                    state["native"].status()
+                torch.cuda.synchronize()
+            except DistError as exc:
+                ok, extras[f"{state['transport']}_first_step_error"] = False, str(exc)
+            same = c_digest_agrees()
+            if ok and not same:
+                extras[f"{state['transport']}_first_step_error"] = "the ranks' C differ after the first step"
+            return agree(ok and same)
+
         streams = TorchStreams(torch, compute)
 
         def own_columns_only():
             # this rank's band multiplications with nothing travelling behind them
-            for c0, c1 in my_cols:
+            for c0, c1 in state["my_cols"]:
                 local_gemm(ta, tb, gm, c1 - c0, gk, 1.0, ops.a, ops.lda, ops.b + (c0 * ops.ldb if tb == "n" else c0), ops.ldb, 0.0,
                            ops.c + c0 * gm, gm)
 
         def step():
             if not gather:
                 own_columns_only()
-            elif native is not None:
-                native.gathered_gemm(ta, tb, gm, gn, gk, 1.0, ops.a, ops.lda, ops.b, ops.ldb, 0.0, ops.c, gm, window,
-                                     args.bands if transport == "mesh" else bands)
+            elif state["native"] is not None:
+                state["native"].gathered_gemm(ta, tb, gm, gn, gk, 1.0, ops.a, ops.lda, ops.b, ops.ldb, 0.0, ops.c, gm, state["window"],
+                                              args.bands if state["transport"] == "mesh" else state["bands"])
             else:
                 gathered_gemm(staged, local_gemm, rank, world, ta, tb, gm, gn, gk, 1.0, ops.a, ops.lda, ops.b, ops.ldb, 0.0,
-                              ops.c, ops.tc_t, bands=bands, streams=streams)
+                              ops.c, ops.tc_t, bands=state["bands"], streams=streams)
 
+        order = []
+        if gather and want in ("auto", "mesh"):
+            order.append("mesh")
+        if gather and want in ("auto", "rccl") and not args.rehearse:
+            order.append("rccl")
+        order.append("torch")
+        for candidate in order:
+            if set_up(candidate) and (not gather or proves_itself()):
+                break
+            close_native()
+        native, window, transport, bands, my_cols = (state[k] for k in ("native", "window", "transport", "bands", "my_cols"))
+        if not gather:
+            transport = "none"
         bm, bn = gm, gn // world
     else:
         if world > 1:  # weak: 2-D C blocks, every block a full size^3 product, nothing exchanged

@@ -304,6 +304,11 @@ const char* sbamd_status_string(int status) {
     case SBAMD_TRSM_INVALID_TRANS: return "invalid Transpose argument";
     case SBAMD_TRSM_INVALID_DIAG: return "invalid Diagonal argument";
     case SBAMD_SCRATCH_TOO_SMALL: return "scratch demand exceeds the fixed array of the no-allocation entry point";
+    // the multi-GPU layer's codes (include/sbamd_dist.h)
+    case 19: return "RCCL call failed or librccl could not be loaded";
+    case 20: return "a peer did not arrive in time";
+    case 21: return "the caller's all-gather callback failed";
+    case 22: return "the communicator lacks the transport or window the operation needs";
     default: return "unknown status";
   }
 }

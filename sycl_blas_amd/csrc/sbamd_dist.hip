@@ -124,6 +124,7 @@ struct sbamd_comm_s {
   uint32_t* status = nullptr;  // device word: bit 0 = a wait timed out
   int64_t timeout_ticks = 0;
   int push_blocks = 16;
+  bool fault_mute = false;  // SBAMD_DIST_FAULT=mute: this rank never signals (fault injection for the callers' fallback paths)
   void* ws = nullptr;
   size_t ws_bytes = 0;
   PeerTable peer_ws = {};
@@ -320,7 +321,7 @@ int check_window(sbamd_comm_t c, int window, const void* ptr, size_t bytes) {
 int mesh_barrier(sbamd_comm_t c, hipStream_t stream) {
   if (c->world == 1) return SBAMD_OK;
   const uint64_t e = ++c->epoch;
-  hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, stream, c->peer_flags, c->rank, c->world, e);
+  if (!c->fault_mute) hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, stream, c->peer_flags, c->rank, c->world, e);
   hipLaunchKernelGGL(mesh_wait_kernel, dim3(1), dim3(64), 0, stream, c->flags, c->rank, c->world, e, c->timeout_ticks,
                      c->status);
   hipError_t err = hipGetLastError();
@@ -713,6 +714,8 @@ int sbamd_dist_create(sbamd_comm_t* out, sbamd_handle_t h, int rank, int world, 
   const char* tmo = std::getenv("SBAMD_DIST_TIMEOUT_MS");
   const int64_t ms = tmo ? std::max<int64_t>(1, std::atoll(tmo)) : 20000;
   c->timeout_ticks = ms * 100000;  // the constant-rate clock runs at 100 MHz
+  const char* fault = std::getenv("SBAMD_DIST_FAULT");
+  c->fault_mute = fault && std::strcmp(fault, "mute") == 0;
   const char* pb = std::getenv("SBAMD_DIST_PUSH_BLOCKS");
   if (pb && std::atoi(pb) > 0) c->push_blocks = std::min(std::atoi(pb), 256);
   DeviceGuard guard(h->impl.device);

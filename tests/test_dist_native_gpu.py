@@ -64,3 +64,20 @@ def test_bench_rehearsal_runs_the_mesh_transport():
     strong = line["extras"]["strong"]
     assert line["config"]["transport"] == "mesh" and strong["transport"] == "mesh"
     assert strong["gathered_c_identical_on_all_ranks"] and strong["peer_part_equals_local_recompute"]
+
+
+def test_bench_drops_a_transport_that_fails_its_first_step():
+    """A rank that never signals (fault injection) makes every mesh barrier time out: bench.py's untimed first step
+    must notice (status of the communicator, C compared over the ranks), drop the mesh transport on ALL ranks and
+    carry on with the next one, with its assertions on the gathered C still holding."""
+    import json
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SBAMD_DIST_FAULT="mute", SBAMD_DIST_TIMEOUT_MS="300")
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--size", "1024", "--steps", "2",
+               "--warmup", "1"], timeout=400, env=env)
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    strong = line["extras"]["strong"]
+    assert line["config"]["transport"] == "torch"
+    assert "did not arrive in time" in line["extras"]["mesh_first_step_error"]
+    assert strong["gathered_c_identical_on_all_ranks"] and strong["peer_part_equals_local_recompute"]
