@@ -333,16 +333,17 @@ struct CostModel<float> {
   static constexpr double small_k[4] = {0.0140, 0.0290, 0.0435, 0.0597};
   static constexpr double large_k[2] = {0.0565, 0.1160};
   static constexpr double huge_k[1] = {0.2200};  // 256 x 256 tile
-  // 96 x 96 tile on the 16x16x4 instruction, one / two workgroups per unit (compiled loop; 3072^3, 1024 tiles:
-  // 462 us -> 0.0744; 1536^3, 256 tiles: 64.5 us)
-  static constexpr double medium_k[2] = {0.0400, 0.0748};
+  // 96 x 96 tile on the 16x16x4 instruction, one / two workgroups per unit (assembly loop; 1536^3, 256 tiles:
+  // 53.0 us -> 0.0314; 3072^3, 1024 tiles: 390 us -> 0.0627; 6144^3: 3054 us -> 0.0621)
+  static constexpr double medium_k[2] = {0.0314, 0.0625};
   // 192 x 192 tile on the same instruction, eight wavefronts of 96 x 48, one workgroup per unit (3072^3, 256 tiles:
-  // 418 us; 6144^3, 1024 tiles: 3300 us -> 0.1345)
-  static constexpr double wide_k[1] = {0.1350};
+  // 388 us -> 0.1247; 6144^3, 1024 tiles: 3047 us -> 0.1240)
+  static constexpr double wide_k[1] = {0.1245};
+  static constexpr double medium_margin = 1.03;  // what the two tiles above must win by (short K with a partly filled last round reads up to 30 % over their model: 1024 x 6272 x 512)
   // two K halves in one workgroup, relative to two resident workgroups of the tile {64x64, 128x128}: 64 x 64 the
   // fit's median over the sweep; 128 x 128 from long launches (8192^3 0.960, 6144^3 0.966, 4096^3 0.976,
   // 2048 x 2048 x 16384 0.952)
-  static constexpr double halves_factor[3] = {0.981, 0.965, 0.98};  // third: the 96 x 96 tile
+  static constexpr double halves_factor[3] = {0.981, 0.965, 1.05};  // third: the 96 x 96 tile (1536^3: 55.3 us against 53.0 in one set)
   // four K quarters in one workgroup of four one-wave sets on the 32 x 32 tile: microseconds per unit of a
   // quarter's K and per round of workgroups over the units, and the launch's fixed part (512^3: 7.3 us,
   // 512 x 512 x 2048: 16.5; 640^3, two rounds: 11.2; 1024 x 1024 x 512, four rounds: 16.0)
@@ -362,6 +363,7 @@ struct CostModel<double> {
   // 96 x 96 (3072^3: 838 us -> 0.1354 for two per unit) and 192 x 192 (3072^3: 807 us; 6144^3: 6350 us -> 0.2584)
   static constexpr double medium_k[2] = {0.0705, 0.1360};
   static constexpr double wide_k[1] = {0.2600};
+  static constexpr double medium_margin = 1.03;  // compiled loops, constants from two shapes each
   static constexpr double halves_factor[3] = {0.800, 0.998, 0.90};
   // (512^3: 9.8 us, 512 x 512 x 2048: 26.2; 640^3: 16.6; 768^3, three rounds: 25.5)
   static constexpr double quarter_k = 0.0428, quarter_over = 4.3;
@@ -443,9 +445,9 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
   }
   // The 96 x 96 and 192 x 192 tiles: where the other tile counts quantise badly over the units (fp32 1536^3: 576
   // tiles of 64 x 64 are three on the busiest unit, 256 tiles of 96 x 96 one each: 84 -> 65 us; 3072^3: 256 tiles
-  // of 192 x 192, 489 -> 415 us).  Their constants come from fewer shapes than the others', so they have to win by 3 %.
+  // of 192 x 192, 489 -> 388 us).  They have to win by CostModel::medium_margin.
   for (int tile : {TILE_96, TILE_192}) {
-    const double us = 1.03 * estimate_us<T>(tile, 1, m, n, k, batch, cus);
+    const double us = CostModel<T>::medium_margin * estimate_us<T>(tile, 1, m, n, k, batch, cus);
     if (us < best_us) best_us = us, best = {tile, 1};
   }
   if (batch != 1) return best;
@@ -460,7 +462,7 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
     for (int depth : depths) {
       if (k / depth < 64) break;                                                   // slabs of at least 64
       if (double(m) * double(n) * depth * sizeof(T) > cube_limit) break;           // cube of at most 1 GiB (or what the caller provides)
-      const double us = (tile > TILE_256 ? 1.03 : 1.0) * estimate_us<T>(tile, depth, m, n, k, 1, cus);
+      const double us = (tile > TILE_256 ? CostModel<T>::medium_margin : 1.0) * estimate_us<T>(tile, depth, m, n, k, 1, cus);
       if (us < split_us) split_us = us, split = {tile, depth};
     }
   Plan chosen = split_us < 0.9 * best_us ? split : best;
@@ -480,7 +482,7 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
     // that leave the last round of two-per-unit workgroups half empty (fp32 6144^3: 2304 tiles are nine per unit,
     // 148 TFLOP/s this way against 132).
     if (tile != TILE_128 && ceil_div(m, edge) * ceil_div(n, edge) * 2 > int64_t(cus) * occ) continue;
-    const double us = (tile == TILE_96 ? 1.03 : 1.0) * estimate_us<T>(tile, 2, m, n, k, 1, cus, true);
+    const double us = (tile == TILE_96 ? CostModel<T>::medium_margin : 1.0) * estimate_us<T>(tile, 2, m, n, k, 1, cus, true);
     // 4 % suffices here, 2 % for the 128 x 128 tile, whose model is built from long launches (a cut through the
     // cube has to win 10 %): the cut is always in two equal halves, whatever the device, and costs neither a
     // second launch nor a trip through memory

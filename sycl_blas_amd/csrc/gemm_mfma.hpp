@@ -636,8 +636,8 @@ struct GemmBody {
   // block addresses global memory as a scalar base (the tile's origin) plus a 32-bit per-lane offset: taken
   // whenever the leading dimensions keep those offsets below 2^32.
   using KL = KLoop<T, BM, BN, BK, WM, WN, TA, TB>;
-  static constexpr bool KLOOP_ASM = SBAMD_KLOOP_ASM && !SBAMD_ABLATE && std::is_same<MS, Mfma<T>>::value && KL::available &&
-                                    KL::MI == K::MI && KL::NI == K::NI;
+  static constexpr bool KLOOP_ASM = SBAMD_KLOOP_ASM && !SBAMD_ABLATE && KL::available && KL::MI == K::MI && KL::NI == K::NI &&
+                                    (KL::SMALL ? std::is_same<MS, MfmaF32Small>::value : std::is_same<MS, Mfma<T>>::value);
   template <int NS>
   __device__ inline int run_kloop_asm(const GemmArgs<T>& g, const T* a, const T* b, int64_t m0, int64_t n0, int64_t k_begin,
                                       int nfull, SBAMD_LDS T* smem, int tid, int a_mn, int b_mn, T (&fa)[NS][K::MI][M::GS],
@@ -678,8 +678,28 @@ struct GemmBody {
       const int lk_a = A_KM && GS == 2 ? 2 * lk : lk, lk_b = B_KM && GS == 2 ? 2 * lk : lk;
       const uint32_t rda = lds0 + uint32_t(A_KM ? (a_mn * LoadA::S + lk_a) * ES : (lk * LoadA::S + a_mn) * ES);
       const uint32_t rdb = lds0 + uint32_t(K::A_ELEMS * ES) + uint32_t(B_KM ? (b_mn * LoadB::S + lk_b) * ES : (lk * LoadB::S + b_mn) * ES);
-      const uint32_t wra = lds0 + uint32_t(((tid / LoadA::PER_ROW) * LoadA::S + (tid % LoadA::PER_ROW) * V) * ES);
-      const uint32_t wrb = lds0 + uint32_t(K::A_ELEMS * ES) + uint32_t(((tid / LoadB::PER_ROW) * LoadB::S + (tid % LoadB::PER_ROW) * V) * ES);
+      // every per-lane input in one register tuple (the block names the registers)
+      typename KL::lane_t lanes;
+#pragma unroll
+      for (int i = 0; i < KL::LANE_N; ++i) lanes[i] = 0;
+#pragma unroll
+      for (int i = 0; i < KL::NVA; ++i) lanes[KL::L_GOA + i] = goa[i];
+#pragma unroll
+      for (int i = 0; i < KL::NVB; ++i) lanes[KL::L_GOB + i] = gob[i];
+      lanes[KL::L_RDA] = rda;
+      lanes[KL::L_RDB] = rdb;
+      // LDS address of the lane's vector i of a tile (TileLoader::store_one); one per operand where the others
+      // follow by a constant, one per vector where a row's vectors do not divide the workgroup
+#pragma unroll
+      for (int i = 0; i < KL::NWA; ++i) {
+        const int v = tid + i * K::NT;
+        lanes[KL::L_WRA + i] = lds0 + uint32_t(((v / LoadA::PER_ROW) * LoadA::S + (v % LoadA::PER_ROW) * V) * ES);
+      }
+#pragma unroll
+      for (int i = 0; i < KL::NWB; ++i) {
+        const int v = tid + i * K::NT;
+        lanes[KL::L_WRB + i] = lds0 + uint32_t(K::A_ELEMS * ES) + uint32_t(((v / LoadB::PER_ROW) * LoadB::S + (v % LoadB::PER_ROW) * V) * ES);
+      }
       typename KL::acc_t accv[KL::ACC_CHUNKS];
       typename KL::sta_t sta;
       typename KL::stb_t stb;
@@ -713,8 +733,7 @@ struct GemmBody {
 #pragma unroll
           for (int e = 0; e < GS; ++e) fbv[s][j * GS + e] = fb[s][j][e];
       }
-      KL::run(accv, sta, stb, fav, fbv, goa, gob, rda, rdb, wra, wrb, base_a, base_b, step_a, step_b,
-              __builtin_amdgcn_readfirstlane(iters));
+      KL::run(accv, sta, stb, fav, fbv, lanes, base_a, base_b, step_a, step_b, __builtin_amdgcn_readfirstlane(iters));
 #pragma unroll
       for (int i = 0; i < K::MI; ++i)
 #pragma unroll

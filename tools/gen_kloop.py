@@ -33,22 +33,29 @@ class Operand:
         elems = mn * self.S if kmajor else cfg.bk * self.S
         self.elems = (elems + 3) & ~3
         self.nv = mn * cfg.bk // cfg.V // cfg.NT
-        assert self.nv in (1, 2, 4) and mn * cfg.bk % (cfg.V * cfg.NT) == 0
+        assert self.nv in (1, 2, 3, 4) and mn * cfg.bk % (cfg.V * cfg.NT) == 0
         self.per_row = cfg.bk // cfg.V if kmajor else mn // cfg.V
-        assert cfg.NT % self.per_row == 0
-        self.rows_per_vec = cfg.NT // self.per_row  # rows of the image between a thread's vectors i and i + 1
+        # rows of the image between a thread's vectors i and i + 1 -- unless a row's vector count does not divide
+        # the workgroup (96 and 192 wide M/N-contiguous tiles): then every vector has a per-lane LDS address of its own
+        self.per_lane_wr = cfg.NT % self.per_row != 0
+        self.rows_per_vec = cfg.NT // self.per_row
+        self.nw = self.nv if self.per_lane_wr else 1  # write addresses the caller passes
 
 
 class Cfg:
-    def __init__(self, dtype, bm, bn, bk, wm, wn, ta, tb, ga):
+    def __init__(self, dtype, bm, bn, bk, wm, wn, ta, tb, ga, small=False):
+        """small: fp32 on v_mfma_f32_16x16x4_f32 (MfmaF32Small in gemm_mfma.hpp: the 96 x 96 and 192 x 192 tiles)"""
         self.dtype, self.bm, self.bn, self.bk, self.wm, self.wn, self.ta, self.tb, self.ga = dtype, bm, bn, bk, wm, wn, ta, tb, ga
+        self.small = small
         f32 = dtype == "float"
+        assert f32 or not small
         self.esz = 4 if f32 else 8
         self.V = 16 // self.esz
-        self.T = 32 if f32 else 16          # edge of a matrix tile
-        self.accr = 16 if f32 else 8        # registers of one accumulator tile
-        self.gs = 2 if f32 else 1           # matrix instructions per tile and fragment group
-        self.pad_mn = 0 if f32 else 16
+        self.T = 32 if f32 and not small else 16              # edge of a matrix tile
+        self.accr = 4 if small else (16 if f32 else 8)        # registers of one accumulator tile
+        self.gs = 2 if f32 and not small else 1               # matrix instructions per tile and fragment group
+        self.fregs = 1 if small else 2                        # registers of one tile's fragment of a group
+        self.pad_mn = 16 if small or not f32 else 0
         self.NT = wm * wn * 64
         self.mi, self.ni = bm // wm // self.T, bn // wn // self.T
         self.ngrp = bk // 4
@@ -60,13 +67,27 @@ class Cfg:
         self.stage = (self.A.elems + self.B.elems) * self.esz
         # ---- register map
         self.nacc = self.mi * self.ni * self.accr
-        self.chunk = min(32, self.nacc)     # accumulator registers per asm operand
-        assert self.nacc % self.chunk == 0
-        self.set_regs = 2 * (self.mi + self.ni)
+        # accumulator registers per asm operand: the largest register-tuple size that divides them
+        # (power-of-two tuples only: hipcc keeps a 12-element vector in scratch memory)
+        self.chunk = next(c for c in (32, 16, 8, 4) if self.nacc % c == 0)
+        # the fragments of A and of B of one set are asm operands too: power-of-two tuples, which also keeps every
+        # tuple at an even register as this part requires
+        pow2 = lambda n: 1 << (n - 1).bit_length()  # noqa: E731
+        self.fa_w, self.fb_w = pow2(self.fregs * self.mi), pow2(self.fregs * self.ni)
+        self.fb_off = self.fa_w
+        self.set_regs = max(2, self.fa_w + self.fb_w)
+        self.sta_w, self.stb_w = pow2(4 * self.A.nv), pow2(4 * self.B.nv)
         self.frag0 = self.nacc
         self.st_a = self.frag0 + self.nsets * self.set_regs
-        self.st_b = self.st_a + 4 * self.A.nv
-        self.temp0 = self.st_b + 4 * self.B.nv
+        self.st_b = self.st_a + self.sta_w
+        # the per-lane inputs, one register tuple: global offsets of A's and B's vectors, read bases, write bases
+        self.lane0 = self.st_b + self.stb_w
+        names = ([f"goa{i}" for i in range(self.A.nv)] + [f"gob{i}" for i in range(self.B.nv)] + ["rda", "rdb"] +
+                 [f"wra{i}" for i in range(self.A.nw)] + [f"wrb{i}" for i in range(self.B.nw)])
+        self.lane_n = next(c for c in (4, 8, 16) if c >= len(names))
+        self.lane = {nm: self.lane0 + q for q, nm in enumerate(names)}
+        self.lane_names = names
+        self.temp0 = self.lane0 + self.lane_n
         self.temps = []  # (register, setup instruction)
         nxt = self.temp0
         self.rd = {}
@@ -81,7 +102,27 @@ class Cfg:
         writes wr[name][(vector, buf)].  A register is shared wherever an immediate can carry the difference."""
         f32 = self.dtype == "float"
         rd, wr = {}, {}
-        if f32 and not op.kmajor:
+        rd_in, wr_in = f"v{self.lane['rd' + name]}", f"v{self.lane['wr' + name + '0']}"
+        if self.small:
+            # ds_read_b32 with a 16-bit byte offset
+            tile_step = 16 * op.S * 4 if op.kmajor else 16 * 4
+            grp_step = 16 if op.kmajor else 4 * op.S * 4
+            top = (ntiles - 1) * tile_step + (self.ngrp - 1) * grp_step + self.stage
+            per_buf = top > 65535
+            for buf in range(2):
+                if buf == 0:
+                    r = self.lane["rd" + name]
+                elif not per_buf:
+                    r = rd[(0, 0)]
+                else:
+                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {self.stage}, {rd_in}"))
+                    r = nxt
+                    nxt += 1
+                for t in range(ntiles):
+                    rd[(t, buf)] = r
+            self.rd_buf_imm = getattr(self, "rd_buf_imm", {})
+            self.rd_buf_imm[name] = not per_buf
+        elif f32 and not op.kmajor:
             # ds_read2st64_b32: offsets in units of 256 B, 8 bits -> tiles (128 B apart) need their own base
             assert op.S * 4 % 256 == 0 and self.stage % 256 == 0
             top = (4 * (self.ngrp - 1) + 2) * (op.S * 4 // 256) + self.stage // 256
@@ -91,7 +132,7 @@ class Cfg:
                     if buf == 1 and not per_buf:
                         rd[(t, 1)] = rd[(t, 0)]
                         continue
-                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {128 * t + buf * self.stage}, %[rd{name}]"))
+                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {128 * t + buf * self.stage}, {rd_in}"))
                     rd[(t, buf)] = nxt
                     nxt += 1
             self.rd_buf_imm = getattr(self, "rd_buf_imm", {})
@@ -106,7 +147,7 @@ class Cfg:
                 if buf == 1 and not per_buf:
                     r = rd[(0, 0)]
                 else:
-                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {buf * self.stage}, %[rd{name}]"))
+                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {buf * self.stage}, {rd_in}"))
                     r = nxt
                     nxt += 1
                 for t in range(ntiles):
@@ -115,11 +156,24 @@ class Cfg:
             self.rd_buf_imm[name] = not per_buf
         self.rd[name] = rd
         vec_step = op.rows_per_vec * op.S * self.esz
-        if f32 and op.kmajor:
+        if op.per_lane_wr:
+            # a per-lane address for every vector (passed in); the other buffer by immediate where it fits
+            per_buf = self.stage + 16 > 65535
+            for i in range(op.nv):
+                wr[(i, 0)] = self.lane[f"wr{name}{i}"]
+                if per_buf:
+                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {self.stage}, v{wr[(i, 0)]}"))
+                    wr[(i, 1)] = nxt
+                    nxt += 1
+                else:
+                    wr[(i, 1)] = wr[(i, 0)]
+            self.wr_imm = getattr(self, "wr_imm", {})
+            self.wr_imm[name] = not per_buf
+        elif f32 and op.kmajor and not self.small:
             # ds_write2_b32: 8-bit offsets only -> one base per (vector, buffer)
             for i in range(op.nv):
                 for buf in range(2):
-                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {i * vec_step + buf * self.stage}, %[wr{name}]"))
+                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {i * vec_step + buf * self.stage}, {wr_in}"))
                     wr[(i, buf)] = nxt
                     nxt += 1
             self.wr_imm = getattr(self, "wr_imm", {})
@@ -131,7 +185,7 @@ class Cfg:
                 if buf == 1 and not per_buf:
                     r = wr[(0, 0)]
                 else:
-                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {buf * self.stage}, %[wr{name}]"))
+                    self.temps.append((nxt, f"v_add_u32 v{nxt}, {buf * self.stage}, {wr_in}"))
                     r = nxt
                     nxt += 1
                 for i in range(op.nv):
@@ -146,7 +200,7 @@ class Cfg:
         return (i * self.ni + j) * self.accr
 
     def frag(self, s, name, t):
-        return self.frag0 + s * self.set_regs + (2 * t if name == "a" else 2 * self.mi + 2 * t)
+        return self.frag0 + s * self.set_regs + (self.fregs * t if name == "a" else self.fb_off + self.fregs * t)
 
     # ---- instruction text
     def reads(self, g, buf):
@@ -159,7 +213,10 @@ class Cfg:
                 d = self.frag(s, name, t)
                 base = self.rd[name][(t, buf)]
                 bufoff = buf * self.stage if self.rd_buf_imm[name] else 0
-                if f32 and not op.kmajor:
+                if self.small:
+                    off = (t * 16 * op.S + 4 * g) * 4 if op.kmajor else (4 * g * op.S + t * 16) * 4
+                    out.append(("lds", f"ds_read_b32 v{d}, v{base} offset:{off + bufoff}"))
+                elif f32 and not op.kmajor:
                     unit = op.S * 4 // 256
                     o0 = 4 * g * unit + bufoff // 256
                     out.append(("lds", f"ds_read2st64_b32 v[{d}:{d + 1}], v{base} offset0:{o0} offset1:{o0 + 2 * unit}"))
@@ -181,13 +238,20 @@ class Cfg:
                 r = st + 4 * i
                 base = self.wr[name][(i, buf)]
                 piece = [("vmwait", (name, i))]
-                if f32 and op.kmajor:
+                if op.per_lane_wr:
+                    piece.append(("lds", f"ds_write_b128 v{base}, v[{r}:{r + 3}] offset:{buf * self.stage if self.wr_imm[name] else 0}"))
+                elif self.small and op.kmajor:
+                    # rows of 34 floats: 8-byte aligned only
+                    off = i * op.rows_per_vec * op.S * 4 + (buf * self.stage if self.wr_imm[name] else 0)
+                    piece.append(("lds", f"ds_write_b64 v{base}, v[{r}:{r + 1}] offset:{off}"))
+                    piece.append(("lds", f"ds_write_b64 v{base}, v[{r + 2}:{r + 3}] offset:{off + 8}"))
+                elif f32 and op.kmajor:
                     piece.append(("lds", f"ds_write2_b32 v{base}, v{r}, v{r + 2} offset1:1"))
                     piece.append(("lds", f"ds_write2_b32 v{base}, v{r + 1}, v{r + 3} offset0:2 offset1:3"))
                 else:
                     off = i * op.rows_per_vec * op.S * self.esz + (buf * self.stage if self.wr_imm[name] else 0)
                     piece.append(("lds", f"ds_write_b128 v{base}, v[{r}:{r + 3}] offset:{off}"))
-                piece.append(("vmem", (name, i), f"global_load_dwordx4 v[{r}:{r + 3}], %[{goff}{i}], {sbase}"))
+                piece.append(("vmem", (name, i), f"global_load_dwordx4 v[{r}:{r + 3}], v{self.lane[goff + str(i)]}, {sbase}"))
                 out.append(piece)
         return out
 
@@ -199,7 +263,9 @@ class Cfg:
             for i in range(self.mi):
                 for j in range(self.ni):
                     a = self.acc(i, j)
-                    if f32:
+                    if self.small:
+                        out.append(f"v_mfma_f32_16x16x4_f32 v[{a}:{a + 3}], v{self.frag(s, 'b', j)}, v{self.frag(s, 'a', i)}, v[{a}:{a + 3}]")
+                    elif f32:
                         out.append(f"v_mfma_f32_32x32x2_f32 v[{a}:{a + 15}], v{self.frag(s, 'b', j) + e}, v{self.frag(s, 'a', i) + e}, v[{a}:{a + 15}]")
                     else:
                         fb, fa = self.frag(s, "b", j), self.frag(s, "a", i)
@@ -269,7 +335,8 @@ class Cfg:
                 regs = set()
                 for name, ntiles in (("a", self.mi), ("b", self.ni)):
                     for t in range(ntiles):
-                        regs.add(f"v[{self.frag(s, name, t)}:{self.frag(s, name, t) + 1}]")
+                        d0 = self.frag(s, name, t)
+                        regs.add(f"v{d0}" if self.fregs == 1 else f"v[{d0}:{d0 + 1}]")
                 # latest LDS read into one of these registers before idx
                 last = None
                 for j in range(idx - 1, -1, -1):
@@ -325,15 +392,14 @@ def emit(c):
     asm = "\n".join(f'        "{ln}\\n"' for piece in lines for ln in piece.split("\n"))
     nch = c.nacc // c.chunk
     ops = [f'"+{{v[{q * c.chunk}:{q * c.chunk + c.chunk - 1}]}}"(acc[{q}])' for q in range(nch)]
-    ops.append(f'"+{{v[{c.st_a}:{c.st_a + 4 * c.A.nv - 1}]}}"(sta)')
-    ops.append(f'"+{{v[{c.st_b}:{c.st_b + 4 * c.B.nv - 1}]}}"(stb)')
+    ops.append(f'"+{{v[{c.st_a}:{c.st_a + c.sta_w - 1}]}}"(sta)')
+    ops.append(f'"+{{v[{c.st_b}:{c.st_b + c.stb_w - 1}]}}"(stb)')
     for s in range(c.ga):
         fa, fb = c.frag(s, "a", 0), c.frag(s, "b", 0)
-        ops.append(f'"+{{v[{fa}:{fa + 2 * c.mi - 1}]}}"(fa[{s}])')
-        ops.append(f'"+{{v[{fb}:{fb + 2 * c.ni - 1}]}}"(fb[{s}])')
+        ops.append(f'"+{{v[{fa}:{fa + c.fa_w - 1}]}}"(fa[{s}])')
+        ops.append(f'"+{{v[{fb}:{fb + c.fb_w - 1}]}}"(fb[{s}])')
     ops += ['"+{s[44:45]}"(base_a)', '"+{s[46:47]}"(base_b)', '[iters] "+s"(iters)']
-    ins = [f'[goa{i}] "v"(goa[{i}])' for i in range(c.A.nv)] + [f'[gob{i}] "v"(gob[{i}])' for i in range(c.B.nv)]
-    ins += ['[rda] "v"(rda)', '[rdb] "v"(rdb)', '[wra] "v"(wra)', '[wrb] "v"(wrb)', '"{s[48:49]}"(step_a)', '"{s[50:51]}"(step_b)']
+    ins = [f'"{{v[{c.lane0}:{c.lane0 + c.lane_n - 1}]}}"(lanes)', '"{s[48:49]}"(step_a)', '"{s[50:51]}"(step_b)']
     assert len(ops) + len(ins) <= 30, len(ops) + len(ins)
     clob_regs = list(range(c.frag0 + c.ga * c.set_regs, c.st_a)) + [r for r, _ in c.temps]
     clob = ", ".join(f'"v{r}"' for r in clob_regs)
@@ -344,18 +410,22 @@ def emit(c):
 // vector registers v0..v{c.end - 1} named in the block.
 template <>
 struct KLoop<{c.dtype}, {c.bm}, {c.bn}, {c.bk}, {c.wm}, {c.wn}, {t(c.ta)}, {t(c.tb)}> {{
-  static constexpr bool available = true;
+  static constexpr bool available = true, SMALL = {t(c.small)};  // SMALL: the 16x16x4 fp32 matrix instruction
   static constexpr int MI = {c.mi}, NI = {c.ni}, GA = {c.ga}, NVA = {c.A.nv}, NVB = {c.B.nv};
+  // the per-lane inputs in one register tuple: global byte offsets of the lane's vectors of A and of B, LDS read
+  // bases, LDS write addresses (one per operand, or one per vector where a row's vectors do not divide the workgroup)
+  static constexpr int NWA = {c.A.nw}, NWB = {c.B.nw}, LANE_N = {c.lane_n};
+  static constexpr int L_GOA = {c.lane['goa0'] - c.lane0}, L_GOB = {c.lane['gob0'] - c.lane0}, L_RDA = {c.lane['rda'] - c.lane0}, L_RDB = {c.lane['rdb'] - c.lane0}, L_WRA = {c.lane['wra0'] - c.lane0}, L_WRB = {c.lane['wrb0'] - c.lane0};
+  typedef uint32_t __attribute__((ext_vector_type({c.lane_n}))) lane_t;
   static constexpr int ACC_CHUNKS = {nch}, CHUNK = {c.chunk * 4 // c.esz};  // accumulator elements per asm operand
   typedef {c.ctype(c.chunk)} acc_t;
-  typedef {c.ctype(4 * c.A.nv)} sta_t;
-  typedef {c.ctype(4 * c.B.nv)} stb_t;
-  typedef {c.ctype(2 * c.mi)} fa_t;
-  typedef {c.ctype(2 * c.ni)} fb_t;
+  typedef {c.ctype(c.sta_w)} sta_t;
+  typedef {c.ctype(c.stb_w)} stb_t;
+  typedef {c.ctype(c.fa_w)} fa_t;
+  typedef {c.ctype(c.fb_w)} fb_t;
   static __device__ __forceinline__ void run(acc_t (&acc)[ACC_CHUNKS], sta_t& sta, stb_t& stb, fa_t (&fa)[GA], fb_t (&fb)[GA],
-                                             const uint32_t (&goa)[NVA], const uint32_t (&gob)[NVB], uint32_t rda, uint32_t rdb,
-                                             uint32_t wra, uint32_t wrb, uint64_t base_a, uint64_t base_b, uint64_t step_a,
-                                             uint64_t step_b, int iters) {{
+                                             lane_t lanes, uint64_t base_a, uint64_t base_b, uint64_t step_a, uint64_t step_b,
+                                             int iters) {{
     asm volatile(
 {asm}
         : {", ".join(ops)}
@@ -382,6 +452,9 @@ for ta in (False, True):
         # the smaller fp64 tiles: 128 x 128 x 16 and 64 x 64 x 16 on four wavefronts (16 / 4 matrix tiles each)
         CONFIGS.append(Cfg("double", 128, 128, 16, 2, 2, ta, tb, 1))
         CONFIGS.append(Cfg("double", 64, 64, 16, 2, 2, ta, tb, 1))
+        # the 96 x 96 and 192 x 192 fp32 tiles on the 16x16x4 matrix instruction: wavefront tiles of 3 x 3 and 6 x 3
+        CONFIGS.append(Cfg("float", 96, 96, 32, 2, 2, ta, tb, 1, small=True))
+        CONFIGS.append(Cfg("float", 192, 192, 32, 2, 4, ta, tb, 1, small=True))
 
 
 def main():
@@ -409,7 +482,7 @@ namespace sbamd {
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, bool TA, bool TB>
 struct KLoop {
-  static constexpr bool available = false;
+  static constexpr bool available = false, SMALL = false;
   static constexpr int MI = 0, NI = 0, GA = 0;
 };
 """)
