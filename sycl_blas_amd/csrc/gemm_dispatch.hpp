@@ -360,11 +360,12 @@ struct CostModel<double> {
   static constexpr double small_k[4] = {0.0335, 0.0693, 0.0815, 0.1149};
   static constexpr double large_k[2] = {0.1120, 0.2215};
   static constexpr double huge_k[1] = {0.2200};
-  // 96 x 96 (3072^3: 838 us -> 0.1354 for two per unit) and 192 x 192 (3072^3: 807 us; 6144^3: 6350 us -> 0.2584)
-  static constexpr double medium_k[2] = {0.0705, 0.1360};
-  static constexpr double wide_k[1] = {0.2600};
-  static constexpr double medium_margin = 1.03;  // compiled loops, constants from two shapes each
-  static constexpr double halves_factor[3] = {0.800, 0.998, 0.90};
+  // 96 x 96 (assembly loop; 1536^3: 100.1 us -> 0.0611 alone; 3072^3: 767 us -> 0.1238 for two per unit, 6144^3 0.128)
+  // and 192 x 192 (3072^3: 777 us -> 0.2508; 6144^3: 6079 us -> 0.2473)
+  static constexpr double medium_k[2] = {0.0611, 0.1245};
+  static constexpr double wide_k[1] = {0.2490};
+  static constexpr double medium_margin = 1.03;
+  static constexpr double halves_factor[3] = {0.800, 0.998, 1.01};  // (96 x 96 at 1536^3: 102.6 us against 100.1 in one set)
   // (512^3: 9.8 us, 512 x 512 x 2048: 26.2; 640^3: 16.6; 768^3, three rounds: 25.5)
   static constexpr double quarter_k = 0.0428, quarter_over = 4.3;
   static constexpr CostOverheads over = {6.16, 6.81, 6.25e6, 0.0438};
@@ -405,12 +406,19 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
   const int bk = tile == TILE_256 ? Tiles<T>::HUGE_BK : tile == TILE_128 ? Tiles<T>::LARGE_BK : (tile == TILE_96 || tile == TILE_192) ? Tiles<T>::MEDIUM_BK : Tiles<T>::SMALL_BK;
   const int occ = (tile == TILE_256 || tile == TILE_192) ? 1 : (tile == TILE_128 || tile == TILE_96) ? 2 : 4;
   const double* per_k = tile == TILE_256 ? C::huge_k : tile == TILE_128 ? C::large_k : tile == TILE_96 ? C::medium_k : tile == TILE_192 ? C::wide_k : C::small_k;
+  // slabs are whole K steps, so a cut into `depth` may come out as fewer slabs (K = 1024 into 12: eleven of 96)
+  const int64_t k_slab = bk * ceil_div(k, int64_t(bk) * depth);
+  if (!fused) depth = std::max<int64_t>(1, ceil_div(k, k_slab));
   const int64_t wgs = ceil_div(m, bm) * ceil_div(n, bn) * batch * depth;
   // workgroups the fullest compute unit runs; the sets of a fused workgroup always share a unit
   const int64_t busiest = fused ? ceil_div(wgs / depth, cus) * depth : ceil_div(wgs, cus);
   const int64_t full = busiest / occ, rem = busiest % occ;
   double us_per_k = double(full) * per_k[occ - 1] + (rem ? per_k[rem - 1] : 0.0);
-  const int64_t k_chunk = bk * ceil_div(k, int64_t(bk) * depth);
+  const int64_t k_chunk = k_slab;
+  // a matrix narrower than one 16-byte vector along M or N (vector-shaped products): the tiles load element by
+  // element, about three times the time per K step (1 x 4096 x 4096: the best cut is four times as deep),
+  // and the rounds of resident workgroups wait for memory side by side: a round costs what one workgroup does
+  if (std::min(m, n) < Mfma<T>::V) us_per_k = 3.0 * per_k[0] * double(full + (rem ? 1 : 0));
   if (fused) us_per_k *= C::halves_factor[tile == TILE_128 ? 1 : tile == TILE_96 ? 2 : 0];
   double us = us_per_k * double(k_chunk);
   if (depth > 1 && !fused) {
@@ -492,7 +500,7 @@ inline Plan plan_gemm(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, d
   // the chip with 64 x 64 tiles and too short for a cut through the cube to pay for its second launch, spread over
   // four times as many wavefronts in ONE launch (512^3: fp64 13.8 -> 9.8 us, fp32 11.1 -> 7.3).
   // (not for a sliver of C: its 32 x 32 tiles would be mostly padding)
-  if (k % (4 * Mfma<T>::V) == 0 && k >= 128 && m >= 32 && n >= 32) {
+  if (k % (4 * Mfma<T>::V) == 0 && k >= 128 && m >= 16 && n >= 16) {
     const int64_t rounds = ceil_div(ceil_div(m, 32) * ceil_div(n, 32), int64_t(cus));
     // (a further round of workgroups overlaps the one before it: it adds 0.85 of a round -- fp64 768^3, three
     // rounds: 25.5 us; 640^3, two: 16.6)

@@ -455,6 +455,9 @@ for ta in (False, True):
         # the 96 x 96 and 192 x 192 fp32 tiles on the 16x16x4 matrix instruction: wavefront tiles of 3 x 3 and 6 x 3
         CONFIGS.append(Cfg("float", 96, 96, 32, 2, 2, ta, tb, 1, small=True))
         CONFIGS.append(Cfg("float", 192, 192, 32, 2, 4, ta, tb, 1, small=True))
+        # the same two tiles in fp64 (K step 16)
+        CONFIGS.append(Cfg("double", 96, 96, 16, 2, 2, ta, tb, 1))
+        CONFIGS.append(Cfg("double", 192, 192, 16, 2, 4, ta, tb, 1))
 
 
 def main():
