@@ -414,6 +414,11 @@ inline double estimate_us(int tile, int64_t depth, int64_t m, int64_t n, int64_t
   const int64_t busiest = fused ? ceil_div(wgs / depth, cus) * depth : ceil_div(wgs, cus);
   const int64_t full = busiest / occ, rem = busiest % occ;
   double us_per_k = double(full) * per_k[occ - 1] + (rem ? per_k[rem - 1] : 0.0);
+  // A lone 64 x 64 workgroup on a long K slab of its own streams from HBM (no other workgroup reads the same
+  // addresses at the same time, as the tiles of a single launch do): its K step cannot be shorter than the memory
+  // latency its one step of lookahead has to cover (256 x 256 x 262144 in 16 slabs: 0.018 us per k, not 0.014;
+  // the 128-wide tile with 64 slabs runs 16 % faster there).
+  if (sizeof(T) == 4 && tile == TILE_64 && depth > 1 && !fused && busiest == 1 && k_slab >= 4096) us_per_k = std::max(us_per_k, 0.018);
   const int64_t k_chunk = k_slab;
   // a matrix narrower than one 16-byte vector along M or N (vector-shaped products): the tiles load element by
   // element, about three times the time per K step (1 x 4096 x 4096: the best cut is four times as deep),
