@@ -18,7 +18,11 @@
  *   SBAMD_DIST_RCCL  RCCL collectives (ncclAllGather / ncclReduceScatter) on a
  *                    second stream; librccl is loaded on demand.
  * Where both are available the mesh transport is used unless
- * SBAMD_DIST_PREFER=rccl is set in the environment.
+ * SBAMD_DIST_PREFER=rccl is set in the environment.  Other environment switches,
+ * read when a communicator is created: SBAMD_DIST_TIMEOUT_MS (how long a device-side
+ * wait for a peer may last, default 20000), SBAMD_DIST_PUSH_BLOCKS (workgroups per peer
+ * of the push kernel, default 16), SBAMD_DIST_FAULT=mute (fault injection for callers'
+ * fallback paths: this rank never signals, so every mesh barrier times out).
  *
  * Every entry point is collective: all ranks of the communicator call it with the
  * same arguments (apart from pointers) in the same order.  Calls are asynchronous
