@@ -114,6 +114,7 @@ const char* sbamd_last_error(sbamd_handle_t h);
  * direct-to-LDS kernel where the operands allow it (16-byte aligned, leading dimensions multiples of 8, K >= 32,
  * M / N a multiple of 8 along a contiguous operand), else HUGE falls back to the automatic choice and LARGE to
  * the register-staged 128x128 kernel; SBAMD_KERNEL_LARGE bit 0 = keep the register-staged kernel anyway;
+ * SBAMD_KERNEL_HUGE bit 1 = eight wavefronts of 128x64 per 256x256 tile instead of four of 128x128;
  * split-K bits 16-23 == 1 = K slabs on the register-staged 64x64 tile instead of the direct-to-LDS 128x128 one.
  * SBAMD_KERNEL_AUTO bit 0 = always copy operands the direct-to-LDS kernel cannot take as they lie (odd leading
  * dimension or offset, M / N not a multiple of 8) into padded aligned buffers, where the library would otherwise

@@ -67,33 +67,40 @@ hipError_t launch16_dma(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream
 }
 
 // Which tile family for a 16-bit GEMM: estimated microseconds per family from the costs per unit of K that
-// a compute unit showed on MI355X (bf16 NN sweep, tools/sweep16.py), cheapest wins.
-//   256 x 256 ring kernel, one workgroup per unit: 0.027 us with every unit busy, 0.018 with few (the clock
-//     gives back under load), so a round of r * cus tiles costs 0.018 + 0.009 r^2;
-//   128 x 128 ring kernel, two workgroups per unit: 0.0088 us per tile a unit has to work through;
+// a compute unit showed on MI355X (bf16 NN, tools/sweep16.py), cheapest wins.
+//   256 x 256 ring kernel, one workgroup per unit: 0.0254 us with every unit busy, 0.018 with few (the clock
+//     gives back under load), so a round of r * cus tiles costs 0.018 + 0.009 r^2; a unit holds one such
+//     workgroup, so nothing runs beside a tile's 256 KiB of C going out: 13.4 us per round on top
+//     (8192 x 8192 x 256: 87 us, 54 of them the four epilogues);
+//   128 x 128 ring kernel, two workgroups per unit: 0.0088 us per tile a unit has to work through; with at most
+//     one tile per unit 0.0049 + 0.0039 * (share of the units that have one) -- 1024^3 10.0 us, 1536^3 16.2, 2048^3 23.1;
 //   128 x 128 register-staged (operands the ring kernel cannot take): 0.0193 us for a resident pair, 0.0141
 //     for a workgroup alone;
-//   64 x 64: 0.0079 us alone, 0.0043 per workgroup from four per unit on.
-// 3072^3 (144 big tiles, 56 % of the units) runs 65 us on the big tile against 81 on 128 x 128; 2304^3 40 us on
-// 128 x 128 against 49.
+//   64 x 64: 0.0079 us alone, 0.0043 per workgroup from four per unit on;
+//   the kernels with several workgroups per unit overlap one tile's stores with another's matrix work, but cannot
+//     be faster than C goes out (5 TB/s + 8 us: 8192 x 8192 x 256 on 128 x 128 tiles 65-67 us, x 64: 46 us).
+// Against the measured best of the three families over 18 shapes (768^3 ... 8192^3, 512 x 4096 x 4096, 8192 x 8192 x
+// 64 / 256 / 512, 3000^3) this picks the best one everywhere (within 1 %).
 inline int pick_family16(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, bool ring_ok, double* t_best = nullptr) {
   auto tiles = [&](int64_t b) { return double(ceil_div(m, b) * ceil_div(n, b) * batch); };
   const double kk = double(k);
   const double q256 = tiles(256) / cus, q128 = std::ceil(tiles(128) / cus), q64 = std::ceil(tiles(64) / cus);
   const double whole = std::floor(q256), part = q256 - whole;
-  const double t_huge = 5.0 + kk * (whole * 0.027 + (part > 0.0 ? 0.018 + 0.009 * part * part : 0.0));
-  const double t_large =
-      5.0 + kk * (ring_ok ? 0.0088 * q128
-                          : std::floor(q128 / 2.0) * 0.0193 + (std::fmod(q128, 2.0) != 0.0 ? 0.0141 : 0.0));
+  const double c_out = 8.0 + double(m) * double(n) * double(batch) * 4.0 / 5.0e6;
+  const double t_huge = 5.0 + kk * (whole * 0.0254 + (part > 0.0 ? 0.018 + 0.009 * part * part : 0.0)) + 13.4 * std::ceil(q256);
+  const double ring128 = q128 <= 1.0 ? 0.0049 + 0.0039 * tiles(128) / cus : 0.0088 * q128;
+  const double t_large = std::max(
+      c_out, 5.0 + kk * (ring_ok ? ring128 : std::floor(q128 / 2.0) * 0.0193 + (std::fmod(q128, 2.0) != 0.0 ? 0.0141 : 0.0)));
   const double per64 = q64 <= 1.0 ? 0.0079 : q64 <= 2.0 ? 0.0105 : q64 <= 3.0 ? 0.0147 : 0.0043 * q64;
-  const double t_small = 5.0 + kk * per64;
+  const double t_small = std::max(c_out, 5.0 + kk * per64);
   if (t_best) *t_best = std::min(ring_ok ? t_huge : t_large, std::min(t_large, t_small));
   if (ring_ok && t_huge <= t_large && t_huge <= t_small) return SBAMD_KERNEL_HUGE;
   return t_large <= t_small ? SBAMD_KERNEL_LARGE : SBAMD_KERNEL_SMALL;
 }
 
 // How many K slabs on the 128 x 128 ring kernel (1 = no cut), from the same kind of estimate (tools/sweep16_split.py:
-// within 10 % of the measured time over depths 8 .. 512 on thin shapes): two launches (8 us); a slab's K range at
+// within 10 % of the measured time over depths 8 .. 512 on thin shapes): two launches (6.5 us; 256 x 256 x 2048 in eight
+// slabs: 9.8 us); a slab's K range at
 // 0.0062 us per unit of K while every workgroup has a compute unit to itself, 0.0088 times the workgroups per unit
 // beyond that; never faster than the operands stream (4.7 TB/s with one workgroup per unit, 3.5 with more, and
 // no more than about 23 GB/s per workgroup);
@@ -111,7 +118,7 @@ inline int64_t pick_depth16(int64_t m, int64_t n, int64_t k, int cus, double t_s
     const double q = std::ceil(wgs / cus);
     const double k_part = double(k) / double(d) * (q <= 1.0 ? 0.0062 : 0.0088 * q);
     const double stream = bytes_ab / std::min(q <= 1.0 ? 4.7e6 : 3.5e6, wgs * 23e3);
-    const double t = 8.0 + std::max(k_part, stream) + double(d) * per_slab;
+    const double t = 6.5 + std::max(k_part, stream) + double(d) * per_slab;
     if (t < best_t) best_t = t, best = d;
   }
   return best;
@@ -357,7 +364,18 @@ hipError_t run16(Handle* h, const Problem<uint16_t, TOut>& p, float alpha, float
     if (h->kernel_override == SBAMD_KERNEL_SPLITK) family = SBAMD_KERNEL_SMALL;
   }
   h->last_kernel = family;
-  if (family == SBAMD_KERNEL_HUGE) return launch16_dma<Tag, TOut, DMA_BM, DMA_BN, 2, 4>(g, p.ta, p.tb, h->stream);
+  if (family == SBAMD_KERNEL_HUGE) {
+    // Four wavefronts of 128 x 128 (one per SIMD, 256 accumulator registers each, a third fewer fragment bytes per
+    // flop) measure 0.5-2.8 % ahead of eight of 128 x 64 at 4096^3 and 8192^3 in every layout (same box, interleaved
+    // runs: NN 1362 against 1326 TFLOP/s, NT 1405 / 1371, TT 1360 / 1335, TN 1270 / 1264).  Their epilogue is twice as
+    // long per wavefront, so eight wavefronts stay for short K (8192 x 8192 x 64: 46.9 against 54.2 us) and for tiles
+    // at a ragged edge, which store element by element (3000^3: 68 against 83 us); pinned with bit 1 of the parameter
+    // set they always run.  Same bits either way.
+    const bool four = p.m % DMA_BM == 0 && p.n % DMA_BN == 0 && p.k >= 2048;
+    if (!four || (h->kernel_override == SBAMD_KERNEL_HUGE && (h->kernel_param & 2)))
+      return launch16_dma<Tag, TOut, DMA_BM, DMA_BN, 2, 4>(g, p.ta, p.tb, h->stream);
+    return launch16_dma<Tag, TOut, DMA_BM, DMA_BN, 2, 2>(g, p.ta, p.tb, h->stream);
+  }
   if (family == SBAMD_KERNEL_LARGE) {
     // pinned with bit 0 of the parameter set: keep the register-staged kernel where the ring kernel would run
     const bool keep_staged = h->kernel_override == SBAMD_KERNEL_LARGE && (h->kernel_param & 1);

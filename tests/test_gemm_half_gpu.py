@@ -162,6 +162,7 @@ def test_direct_to_lds_family(sb_handle, pair):
     # K tails (k % 32 != 0: one zero-padded tile behind the ring): shorter and longer than half a K step, behind
     # one ring step and behind many.
     for (m, n, k), ta, tb in itertools.product([(256, 256, 32), (304, 520, 96), (512, 264, 160), (1000, 776, 256), (264, 256, 1024),
+                                                (512, 256, 2048), (256, 512, 2104),  # four wavefronts of 128 x 128
                                                 (256, 256, 33), (304, 520, 100), (512, 264, 1007), (264, 520, 49), (256, 264, 40), (520, 256, 1016)],
                                                "nt", "nt"):
         # a K tail makes the leading dimension of a K-contiguous operand odd: those fall back (16-byte rows needed)
@@ -232,7 +233,9 @@ def test_every_kernel_gives_the_same_bits(sb_handle, pair):
     instruction the same 16 k at a time in the same order, so the outputs have to be identical, K tail included."""
     h = sb_handle
     storage, out_name = pair
-    for (m, n, k), ta, tb in itertools.product([(264, 392, 616), (136, 520, 1000)], "nt", "nt"):
+    # (the last shape -- whole 256 x 256 tiles, K of 2048 and a tail -- takes the four-wavefront grid of the big tile
+    # unless bit 1 of its parameter asks for eight)
+    for (m, n, k), ta, tb in itertools.product([(264, 392, 616), (136, 520, 1000), (256, 512, 2072)], "nt", "nt"):
         rng = seeded("same-bits", pair, m, n, k, ta, tb)
         lda, ldb = (k if ta != "n" else m), (n if tb != "n" else k)
         a_bits, _ = make_inputs(rng, m * k, storage)
@@ -255,7 +258,7 @@ def test_every_kernel_gives_the_same_bits(sb_handle, pair):
         try:
             base, ran = run(_lib.KERNEL_SMALL, 0)
             assert ran == _lib.KERNEL_SMALL
-            for family, param in [(_lib.KERNEL_LARGE, 0), (_lib.KERNEL_LARGE, 1), (_lib.KERNEL_HUGE, 0)]:
+            for family, param in [(_lib.KERNEL_LARGE, 0), (_lib.KERNEL_LARGE, 1), (_lib.KERNEL_HUGE, 0), (_lib.KERNEL_HUGE, 2)]:
                 got, ran = run(family, param)
                 assert ran == family and np.array_equal(got, base), (pair, m, n, k, ta, tb, family, param)
             ring, ran = run(_lib.KERNEL_SPLITK, 3)

@@ -25,15 +25,18 @@ def main():
     torch.cuda.set_stream(side)
     h = C.c_void_p()
     assert lib.sbamd_create(C.byref(h), 0, C.c_void_p(side.cuda_stream)) == 0
-    fams = [("auto", _lib.KERNEL_AUTO), ("huge", _lib.KERNEL_HUGE), ("large", _lib.KERNEL_LARGE), ("small", _lib.KERNEL_SMALL)]
+    # (label, family, parameter); HUGE with bit 1 set: eight wavefronts per 256 x 256 tile instead of four
+    fams = [("auto", _lib.KERNEL_AUTO, 0), ("huge", _lib.KERNEL_HUGE, 0), ("huge/8 waves", _lib.KERNEL_HUGE, 2),
+            ("large", _lib.KERNEL_LARGE, 0), ("small", _lib.KERNEL_SMALL, 0), ("K cut 8", _lib.KERNEL_SPLITK, 8),
+            ("K cut 16", _lib.KERNEL_SPLITK, 16)]
     for (m, n, k) in shapes:
         a = (torch.rand(m * k, device="cuda") * 7 - 2).to(dt)
         b = (torch.rand(k * n, device="cuda") * 7 - 2).to(dt)
         c = torch.empty(m * n, device="cuda", dtype=out_dt)
         reps = max(3, min(200, int(4e11 / (2.0 * m * n * k))))
         line = f"{name} {m:5d} x {n:5d} x {k:6d}:"
-        for label, fam in fams:
-            lib.sbamd_set_kernel(h, fam, 0)
+        for label, fam, param in fams:
+            lib.sbamd_set_kernel(h, fam, param)
 
             def call():
                 st = fn(h, b"n", b"n", m, n, k, C.c_float(1.0), C.c_void_p(a.data_ptr()), m, C.c_void_p(b.data_ptr()), k,
