@@ -70,27 +70,30 @@ hipError_t launch16_dma(GemmArgs16<TOut> g, bool ta, bool tb, hipStream_t stream
 // a compute unit showed on MI355X (bf16 NN, tools/sweep16.py), cheapest wins.
 //   256 x 256 ring kernel, one workgroup per unit: 0.0254 us with every unit busy, 0.018 with few (the clock
 //     gives back under load), so a round of r * cus tiles costs 0.018 + 0.009 r^2; a unit holds one such
-//     workgroup, so nothing runs beside a tile's 256 KiB of C going out: 13.4 us per round on top
-//     (8192 x 8192 x 256: 87 us, 54 of them the four epilogues);
-//   128 x 128 ring kernel, two workgroups per unit: 0.0088 us per tile a unit has to work through; with at most
-//     one tile per unit 0.0049 + 0.0039 * (share of the units that have one) -- 1024^3 10.0 us, 1536^3 16.2, 2048^3 23.1;
+//     workgroup, so nothing runs beside a tile's 256 KiB of C going out: 13.4 us per round on top for K <= 256
+//     (8192 x 8192 x 256: 87 us, 54 of them the four epilogues), 9 us for longer K, where the units drift apart
+//     and one's stores meet another's matrix work (8192 x 8192 x 512: 94 us, x 1024: 146, 8192 x 4096 x 1024: 75.5);
+//   128 x 128 ring kernel, two workgroups per unit: 0.0086 us per unit of K and 0.7 us per tile a unit has to work
+//     through (8192 x 8192 x 1024: 160 us, 8192^3: 1132); with at most one tile per unit 0.0049 + 0.0039 * (share of
+//     the units that have one) -- 1024^3 10.0 us, 1536^3 16.2, 2048^3 23.1;
 //   128 x 128 register-staged (operands the ring kernel cannot take): 0.0193 us for a resident pair, 0.0141
 //     for a workgroup alone;
 //   64 x 64: 0.0079 us alone, 0.0043 per workgroup from four per unit on;
 //   the kernels with several workgroups per unit overlap one tile's stores with another's matrix work, but cannot
 //     be faster than C goes out (5 TB/s + 8 us: 8192 x 8192 x 256 on 128 x 128 tiles 65-67 us, x 64: 46 us).
-// Against the measured best of the three families over 18 shapes (768^3 ... 8192^3, 512 x 4096 x 4096, 8192 x 8192 x
-// 64 / 256 / 512, 3000^3) this picks the best one everywhere (within 1 %).
+// Against the measured best of the three families over 24 shapes (768^3 ... 8192^3, 512 x 4096 x 4096, 8192 x 8192 x
+// 64 ... 1024, 1024 x 16384 x 1024, 3000^3) this picks the best one everywhere (within 1 %).
 inline int pick_family16(int64_t m, int64_t n, int64_t k, int64_t batch, int cus, bool ring_ok, double* t_best = nullptr) {
   auto tiles = [&](int64_t b) { return double(ceil_div(m, b) * ceil_div(n, b) * batch); };
   const double kk = double(k);
   const double q256 = tiles(256) / cus, q128 = std::ceil(tiles(128) / cus), q64 = std::ceil(tiles(64) / cus);
   const double whole = std::floor(q256), part = q256 - whole;
   const double c_out = 8.0 + double(m) * double(n) * double(batch) * 4.0 / 5.0e6;
-  const double t_huge = 5.0 + kk * (whole * 0.0254 + (part > 0.0 ? 0.018 + 0.009 * part * part : 0.0)) + 13.4 * std::ceil(q256);
-  const double ring128 = q128 <= 1.0 ? 0.0049 + 0.0039 * tiles(128) / cus : 0.0088 * q128;
+  const double t_huge = 5.0 + kk * (whole * 0.0254 + (part > 0.0 ? 0.018 + 0.009 * part * part : 0.0)) +
+                        (k <= 256 ? 13.4 : 9.0) * std::ceil(q256);
+  const double t_ring128 = q128 <= 1.0 ? 5.0 + kk * (0.0049 + 0.0039 * tiles(128) / cus) : 5.0 + q128 * (kk * 0.0086 + 0.7);
   const double t_large = std::max(
-      c_out, 5.0 + kk * (ring_ok ? ring128 : std::floor(q128 / 2.0) * 0.0193 + (std::fmod(q128, 2.0) != 0.0 ? 0.0141 : 0.0)));
+      c_out, ring_ok ? t_ring128 : 5.0 + kk * (std::floor(q128 / 2.0) * 0.0193 + (std::fmod(q128, 2.0) != 0.0 ? 0.0141 : 0.0)));
   const double per64 = q64 <= 1.0 ? 0.0079 : q64 <= 2.0 ? 0.0105 : q64 <= 3.0 ? 0.0147 : 0.0043 * q64;
   const double t_small = std::max(c_out, 5.0 + kk * per64);
   if (t_best) *t_best = std::min(ring_ok ? t_huge : t_large, std::min(t_large, t_small));
